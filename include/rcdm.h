@@ -1,0 +1,247 @@
+/*
+ * rcdm.h — C-ABI of librcdm_hip.so: the MI355X (gfx950) kernels underneath the RCDMs stage-2
+ * denoiser (UNet3DConditionModel.forward + the CFG/DDIM loop).
+ *
+ * The reference (muzishen/RCDMs) has NO FFI of its own: every op on this path is a torch/ATen call
+ * made from Python.  Each entry point below therefore names the reference Python call site(s) it
+ * replaces (paths relative to the reference repo).  All functions:
+ *   - take plain device pointers + sizes (no torch types), caller-owned buffers, an explicit
+ *     hipStream_t (passed as void*), never allocate, never synchronise, are graph-capturable;
+ *   - return 0 on success, a negative RCDM_E* code otherwise (never throw);
+ *   - compute in fp16 storage / fp32 accumulate ("f16" below = IEEE binary16).
+ *
+ * Activation layout everywhere: channels-last rows.  A tensor the reference holds as
+ * (b, C, f, H, W) is one row-major matrix X[M][ld] with M = b*f*H*W rows ordered (b, f, y, x) and C
+ * contiguous channels per row; `ld` (>= C, multiple of 8) lets a tensor live inside a wider
+ * "concat" buffer so torch.cat([h, skip], dim=1) (unet_blocks.py:644,754) costs nothing.
+ */
+#ifndef RCDM_H
+#define RCDM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCDM_VERSION 0x000100 /* 0.1.0 */
+
+/* error codes */
+#define RCDM_OK 0
+#define RCDM_EINVAL (-1)   /* bad argument (null pointer, negative size, misaligned ld) */
+#define RCDM_ESHAPE (-2)   /* shape not supported by this kernel */
+#define RCDM_ELAUNCH (-3)  /* HIP launch / runtime error (see rcdm_last_hip_error) */
+#define RCDM_EWORKSPACE (-4) /* workspace too small */
+
+/* epilogue flags for rcdm_gemm / rcdm_conv3x3 (applied in fp32, one final rounding to f16) */
+#define RCDM_EPI_BIAS 1      /* + bias[n]                              (fp32 [N])                  */
+#define RCDM_EPI_ROWVEC 2    /* + rowvec[m / rows_per_sample][n]       (fp32, resnet.py:191-194)   */
+#define RCDM_EPI_RESIDUAL 4  /* + residual[m][n]                       (f16, ldr)                  */
+#define RCDM_EPI_GEGLU 8     /* out[m][j] = (h+bh) * gelu(g+bg); W/bias rows packed per 128-row    */
+                             /* tile as 64 h rows then their 64 g rows (see rcdm_pack_geglu_rows)  */
+
+int rcdm_version(void);
+/* last HIP error code seen by this library on this thread (0 = none) and its string */
+int rcdm_last_hip_error(void);
+const char* rcdm_last_hip_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM  out[M][N] = epi( A[M][K] * W[N][K]^T )        replaces: nn.Linear / 1x1 InflatedConv3d calls
+ *   attention.py:121,140-141,164 (to_q/k/v/out), :330,:352 (proj_in/out 1x1 conv),
+ *   motion_module.py:166,170 (proj_in/out), resnet.py:208 (conv_shortcut),
+ *   diffusers FeedForward GEGLU proj + out (attention.py:514, motion_module.py:243).
+ *   A f16 row stride lda; W f16 [N][K] (nn.Linear's own [out,in] layout); K % 8 == 0, N % 8 == 0.
+ *   split_k: 0 = library heuristic, 1 = off, >1 = forced; needs workspace (rcdm_gemm_workspace_bytes).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t M, N, K;
+  int32_t lda, ldc, ldr;      /* row strides in elements (ldr only with RCDM_EPI_RESIDUAL) */
+  int32_t epilogue;           /* RCDM_EPI_* bits */
+  int32_t rows_per_sample;    /* RCDM_EPI_ROWVEC: rowvec row = m / rows_per_sample */
+  int32_t ldt;                /* RCDM_EPI_ROWVEC: rowvec row stride (floats) */
+  float out_scale;            /* out = epi(...) * out_scale   (1/output_scale_factor, resnet.py:210) */
+  int32_t split_k;
+} rcdm_gemm_desc;
+
+size_t rcdm_gemm_workspace_bytes(const rcdm_gemm_desc* d);
+int rcdm_gemm(const rcdm_gemm_desc* d, const void* A, const void* W, const float* bias,
+              const float* rowvec, const void* residual, void* out, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * conv3x3 (pad 1) as implicit GEMM over channels-last rows.   replaces InflatedConv3d.forward
+ *   resnet.py:10-18 with k=3: ResnetBlock3D conv1/conv2 (:188,:205), Downsample3D (:104, stride 2),
+ *   Upsample3D (:65+:78: F.interpolate(nearest, x2) folded into the input indexing, never
+ *   materialised), unet.py:403 conv_in, :457 conv_out.
+ *   in : [n_img*h_in*w_in][lda] f16 (c_in channels used);  W f16 [c_out][9*c_in], k = tap*c_in + c,
+ *   tap = ky*3+kx (i.e. torch weight.permute(0,2,3,1)); out rows = n_img*h_out*w_out where
+ *   h_out = (h_in*(1+upsample) - 1)/stride + 1.  c_in % 8 == 0, c_out % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_img, h_in, w_in, c_in, c_out;
+  int32_t stride;     /* 1 | 2 */
+  int32_t upsample;   /* 0 | 1 */
+  int32_t lda, ldc, ldr;
+  int32_t epilogue;
+  int32_t rows_per_sample, ldt;
+  float out_scale;
+  int32_t split_k;
+} rcdm_conv3x3_desc;
+
+size_t rcdm_conv3x3_workspace_bytes(const rcdm_conv3x3_desc* d);
+int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, const float* bias,
+                 const float* rowvec, const void* residual, void* out, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm (+SiLU).  replaces torch.nn.GroupNorm applied to the 5-D tensor — statistics over
+ *   (C/groups, f, H, W) ACROSS frames — at resnet.py:185-186,196,202 and unet.py:455-456
+ *   (samples = b, rows_per_sample = f*H*W), and the per-frame 4-D form at attention.py:328 and
+ *   motion_module.py:162 (samples = b*f, rows_per_sample = H*W, eps 1e-6, no SiLU).
+ *   Two launches: stats (deterministic fixed-order partials, no float atomics) then apply.
+ *   C % (2*groups) == 0, C % 8 == 0.  stats workspace: rcdm_groupnorm_workspace_bytes.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t samples, rows_per_sample, C, groups;
+  int32_t ldx, ldy;
+  float eps;
+  int32_t silu;  /* 0 | 1 */
+} rcdm_groupnorm_desc;
+
+size_t rcdm_groupnorm_workspace_bytes(const rcdm_groupnorm_desc* d);
+int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float* gamma,
+                        const float* beta, void* y, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (eps 1e-5, torch default) with optional fused positional-encoding add
+ *   replaces nn.LayerNorm at attention.py:482,502,514 and motion_module.py:236,243; with pe != NULL
+ *   also PositionalEncoding.forward motion_module.py:265-267 applied after the "(b f) d c -> (b d) f c"
+ *   regroup (:299-302): y[m] += pe[(m / rows_per_frame) % frames].   C % 8 == 0, C <= 2048.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t M, C, ldx, ldy;
+  float eps;
+  int32_t rows_per_frame, frames; /* only with pe */
+} rcdm_layernorm_desc;
+
+int rcdm_layernorm(const rcdm_layernorm_desc* d, const void* x, const float* gamma,
+                   const float* beta, const float* pe, void* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flash-style multi-head attention, softmax(scale * Q K^T) V, no mask, online softmax in fp32.
+ *   replaces CrossAttention._attention attention.py:170-199 (+ reshape_heads_to_batch_dim :93-105):
+ *   self-attention over the hw latent patches of one frame and cross-attention over the L_text
+ *   context rows of that frame.  Q rows [batch*Lq][ldq] with head h at columns [h*d, (h+1)*d);
+ *   K,V rows [batch*Lk][ldk|ldv]; out [batch*Lq][ldo].  d % 8 == 0, d <= 160.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t batch, heads, Lq, Lk, d;
+  int32_t ldq, ldk, ldv, ldo;
+  float scale;
+} rcdm_attn_desc;
+
+int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const void* V, void* out,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Temporal self-attention over the f frames of every (sample, pixel, head).
+ *   replaces VersatileAttention.forward motion_module.py:294-354 between to_q/k/v and to_out: the
+ *   "(b f) d c -> (b d) f c" regroup, 5x5 softmax(QK^T*scale)V and the inverse regroup become index
+ *   arithmetic.  qkv rows ordered (b, f, pixel), [q | k | v] at columns [0,C) [C,2C) [2C,3C).
+ *   frames <= 8, d % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t samples, frames, pixels, heads, d;
+  int32_t ldqkv, ldo;
+  float scale;
+} rcdm_temporal_attn_desc;
+
+int rcdm_temporal_attn(const rcdm_temporal_attn_desc* d, const void* qkv, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Timestep embedding: diffusers 0.24.0 Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) as used
+ *   at unet.py:100,383: out[r][0:half] = cos(t_r*w_i), out[r][half:] = sin(t_r*w_i),
+ *   w_i = exp(-ln(10000)*i/half).  t fp32 device array [rows]; out fp32 [rows][dim].
+ * ---------------------------------------------------------------------------------------------- */
+int rcdm_timestep_embed(const float* t, int32_t rows, int32_t dim, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tiny-M fp32 linear: out[r][n] = act_out( sum_k act_in(x[r][k]) * W[n][k] + bias[n] ), rows <= 8.
+ *   replaces TimestepEmbedding (linear_1 -> SiLU -> linear_2, unet.py:103,389) and every
+ *   ResnetBlock3D.time_emb_proj(silu(temb)) (resnet.py:191), all 22 batched as one N = sum(Cout).
+ *   W f16 [N][K]; silu_in / silu_out are 0|1.  K % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int rcdm_small_linear(const float* x, int32_t rows, int32_t K, const void* W, const float* bias,
+                      int32_t N, int32_t silu_in, int32_t silu_out, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Assemble the UNet input rows from the sampling-loop state: replaces
+ *   torch.cat([latents]*2) + cat([x, mask, masked_latents], dim=1) RCDMs_pipeline.py:482-486 and the
+ *   NCFHW->channels-last f16 conversion.  latents fp32 (S,4,f,H,W); mask fp32 (reps*S,1,f,H,W);
+ *   masked fp32 (reps*S,4,f,H,W); reps = 2 with CFG (uncond copies first), 1 without.
+ *   out rows [(reps*S)*f*H*W][ld] f16, channels 0..8 written, 9..c_pad-1 zeroed.
+ * ---------------------------------------------------------------------------------------------- */
+int rcdm_assemble_input(const float* latents, const float* mask, const float* masked, int32_t S,
+                        int32_t reps, int32_t frames, int32_t H, int32_t W, void* out, int32_t ld,
+                        int32_t c_pad, void* stream);
+
+/* generic layout converters for UNet3DConditionModel.forward called directly with a 5-D tensor
+ * (unet.py:322-330): fp32 (b,C,f,H,W) -> f16 rows [b*f*H*W][ld] (channels >= C zeroed up to c_pad)
+ * and f16 rows -> fp32 (b,C,f,H,W). */
+int rcdm_ncfhw_to_rows(const float* x, int32_t b, int32_t C, int32_t frames, int32_t H, int32_t W,
+                       void* out, int32_t ld, int32_t c_pad, void* stream);
+int rcdm_rows_to_ncfhw(const void* rows, int32_t ld, int32_t b, int32_t C, int32_t frames, int32_t H,
+                       int32_t W, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused classifier-free guidance + DDIM step (eta = 0, epsilon prediction), in place on `latents`:
+ *   replaces noise_pred.chunk(2); eps = eps_u + s*(eps_c - eps_u) RCDMs_pipeline.py:492-494 and
+ *   diffusers 0.24.0 DDIMScheduler.step (:497):  x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t);
+ *   x' = sqrt(a_prev) x0 + sqrt(1-a_prev) eps.
+ *   eps rows f16 [(reps*S)*f*H*W][ld] (uncond sample block first); latents fp32 (S,4,f,H,W).
+ *   coef: device fp32 table [n_steps][4] = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)};
+ *   step_counter: device int32; the kernel uses row coef[*step_counter] (the counter is advanced by
+ *   rcdm_advance_step so a captured graph replays with no host-side parameter change).
+ * ---------------------------------------------------------------------------------------------- */
+int rcdm_cfg_ddim_step(const void* eps, int32_t ld, float* latents, int32_t S, int32_t reps,
+                       int32_t frames, int32_t H, int32_t W, float guidance_scale, const float* coef,
+                       const int32_t* step_counter, void* stream);
+/* t_out[0..rows) = timesteps[*step_counter] (fp32) — feeds rcdm_timestep_embed inside a graph */
+int rcdm_load_timestep(const float* timesteps, const int32_t* step_counter, float* t_out,
+                       int32_t rows, void* stream);
+int rcdm_advance_step(int32_t* step_counter, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight repacking (fp32 reference layout -> f16 kernel layout), device to device:
+ *   rcdm_pack_f16: elementwise fp32 -> f16.
+ *   rcdm_pack_conv3x3: torch (Cout,Cin,3,3) fp32 -> f16 [Cout][9*cin_pad], k = tap*cin_pad + c.
+ *   rcdm_pack_geglu_rows: FeedForward.net.0.proj weight (8C,K)/bias(8C) -> rows reordered so every
+ *   128-row tile holds 64 "hidden" rows then the matching 64 "gate" rows (RCDM_EPI_GEGLU).
+ * ---------------------------------------------------------------------------------------------- */
+int rcdm_pack_f16(const float* src, void* dst, size_t n, void* stream);
+int rcdm_pack_conv3x3(const float* w, int32_t c_out, int32_t c_in, int32_t cin_pad, void* dst,
+                      void* stream);
+int rcdm_pack_geglu_rows(const float* w, const float* bias, int32_t n_out /*8C*/, int32_t K,
+                         void* w_dst, float* bias_dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * hipGraph plumbing: capture the ~10^3 launches of one denoising step once, replay per step.
+ * ---------------------------------------------------------------------------------------------- */
+int rcdm_graph_begin_capture(void* stream);
+int rcdm_graph_end_capture(void* stream, void** graph_exec_out);
+int rcdm_graph_launch(void* graph_exec, void* stream);
+int rcdm_graph_destroy(void* graph_exec);
+
+/* HIP-event timing on an explicit stream (bench.py roofline leg) */
+int rcdm_event_create(void** ev_out);
+int rcdm_event_record(void* ev, void* stream);
+int rcdm_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on stop */
+int rcdm_event_destroy(void* ev);
+int rcdm_stream_synchronize(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCDM_H */

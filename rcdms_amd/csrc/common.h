@@ -1,0 +1,44 @@
+// common.h — shared types/helpers for the gfx950 kernels of librcdm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rcdm.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+union Pack16 {  // one 16-byte global/LDS transaction seen as 8 halves
+  uint4 u;
+  f16x8 h;
+  f16 e[8];
+};
+
+extern thread_local int g_rcdm_last_hip_error;
+
+static inline int rcdm_check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_rcdm_last_hip_error = (int)e;
+    return RCDM_ELAUNCH;
+  }
+  return RCDM_OK;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as diffusers GEGLU.gelu -> F.gelu(approximate="none")
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

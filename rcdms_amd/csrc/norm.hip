@@ -1,0 +1,266 @@
+// norm.hip — GroupNorm(+SiLU) and LayerNorm(+positional encoding) over channels-last f16 rows,
+// fp32 statistics, wavefront reductions, deterministic (fixed-order partials, no float atomics).
+//
+// Replaces (reference): torch.nn.GroupNorm on the 5-D tensor, i.e. statistics ACROSS the f frames,
+// src/models/resnet.py:185-186,196,202 and unet.py:455-456; the per-frame form
+// attention.py:328 / motion_module.py:162; nn.LayerNorm attention.py:482,502,514,
+// motion_module.py:236,243; PositionalEncoding.forward motion_module.py:265-267.
+#include "common.h"
+
+namespace {
+
+struct GnArgs {
+  const f16* x;
+  f16* y;
+  const float* gamma;
+  const float* beta;
+  float* partial;  // [samples][splits][groups][3] = (count, mean, M2)
+  float* stat;     // [samples][groups][2] = (mean, rstd)
+  int samples, P, C, G, cg, CH, RPB, ldx, ldy, splits, rows_per_split;
+  float eps;
+  int silu;
+};
+
+// grid (splits, samples); block CH*RPB threads; thread (rl, ch) owns 16-B chunk ch of rows rl+k*RPB.
+__global__ void gn_stats_kernel(const GnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* part = (float*)smem;  // [threads][16]
+  const int t = threadIdx.x;
+  const int ch = t % p.CH, rl = t / p.CH;
+  const int s = blockIdx.y, sp = blockIdx.x;
+  const int r_begin = sp * p.rows_per_split;
+  const int r_end = min(p.P, r_begin + p.rows_per_split);
+  float sum[8], sq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
+  const f16* base = p.x + (size_t)s * p.P * p.ldx + ch * 8;
+  for (int r = r_begin + rl; r < r_end; r += p.RPB) {
+    Pack16 v;
+    v.u = *(const uint4*)(base + (size_t)r * p.ldx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)v.e[e];
+      sum[e] += f;
+      sq[e] += f * f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    part[t * 16 + e] = sum[e];
+    part[t * 16 + 8 + e] = sq[e];
+  }
+  __syncthreads();
+  if (t < p.G) {
+    float gs = 0.f, gq = 0.f;
+    for (int r = 0; r < p.RPB; ++r)
+      for (int c = t * p.cg; c < (t + 1) * p.cg; ++c) {
+        const int src = (r * p.CH + (c >> 3)) * 16 + (c & 7);
+        gs += part[src];
+        gq += part[src + 8];
+      }
+    const float n = (float)(r_end - r_begin) * (float)p.cg;
+    const float mean = n > 0.f ? gs / n : 0.f;
+    float m2 = gq - gs * mean;
+    if (m2 < 0.f) m2 = 0.f;
+    float* o = p.partial + (((size_t)s * p.splits + sp) * p.G + t) * 3;
+    o[0] = n;
+    o[1] = mean;
+    o[2] = m2;
+  }
+}
+
+// one thread per (sample, group): Chan's pairwise combination in split order.
+__global__ void gn_finalize_kernel(const GnArgs p) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.samples * p.G) return;
+  const int s = idx / p.G, g = idx - s * p.G;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int sp = 0; sp < p.splits; ++sp) {
+    const float* o = p.partial + (((size_t)s * p.splits + sp) * p.G + g) * 3;
+    const float nb = o[0], mb = o[1], qb = o[2];
+    if (nb > 0.f) {
+      const float nt = n + nb, delta = mb - mean;
+      mean += delta * (nb / nt);
+      m2 += qb + delta * delta * (n * nb / nt);
+      n = nt;
+    }
+  }
+  const float var = n > 0.f ? m2 / n : 0.f;  // biased, as torch.nn.GroupNorm
+  p.stat[idx * 2] = mean;
+  p.stat[idx * 2 + 1] = rsqrtf(var + p.eps);
+}
+
+// grid (blocks_per_sample, samples); same thread->chunk mapping as the stats kernel.
+__global__ void gn_apply_kernel(const GnArgs p) {
+  const int t = threadIdx.x;
+  const int ch = t % p.CH, rl = t / p.CH;
+  const int s = blockIdx.y;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = ch * 8 + e;
+    const int g = c / p.cg;
+    const float mean = p.stat[(s * p.G + g) * 2], rstd = p.stat[(s * p.G + g) * 2 + 1];
+    const float ga = p.gamma[c], be = p.beta[c];
+    sc[e] = rstd * ga;
+    sh[e] = be - mean * rstd * ga;
+  }
+  const f16* xb = p.x + (size_t)s * p.P * p.ldx + ch * 8;
+  f16* yb = p.y + (size_t)s * p.P * p.ldy + ch * 8;
+  for (int r = blockIdx.x * p.RPB + rl; r < p.P; r += gridDim.x * p.RPB) {
+    Pack16 v, o;
+    v.u = *(const uint4*)(xb + (size_t)r * p.ldx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = (float)v.e[e] * sc[e] + sh[e];
+      if (p.silu) f = silu_f(f);
+      o.e[e] = (f16)f;
+    }
+    *(uint4*)(yb + (size_t)r * p.ldy) = o.u;
+  }
+}
+
+int gn_plan(const rcdm_groupnorm_desc* d, GnArgs& a) {
+  if (d->samples <= 0 || d->rows_per_sample <= 0 || d->C <= 0 || d->groups <= 0) return RCDM_EINVAL;
+  if ((d->C & 7) || (d->C % d->groups) || (d->ldx & 7) || (d->ldy & 7)) return RCDM_ESHAPE;
+  if (d->groups > 64 || d->C > 8192) return RCDM_ESHAPE;
+  a.samples = d->samples; a.P = d->rows_per_sample; a.C = d->C; a.G = d->groups;
+  a.cg = d->C / d->groups; a.CH = d->C / 8;
+  a.RPB = 256 / a.CH;
+  if (a.RPB < 1) a.RPB = 1;
+  if (a.CH * a.RPB < a.G) a.RPB = (a.G + a.CH - 1) / a.CH;  // need >= G threads for the group pass
+  a.ldx = d->ldx; a.ldy = d->ldy; a.eps = d->eps; a.silu = d->silu;
+  int splits = (768 + a.samples - 1) / a.samples;
+  const int max_splits = (a.P + 4 * a.RPB - 1) / (4 * a.RPB);  // >= 4 row passes per block
+  if (splits > max_splits) splits = max_splits;
+  if (splits > 256) splits = 256;
+  if (splits < 1) splits = 1;
+  a.rows_per_split = (a.P + splits - 1) / splits;
+  a.splits = (a.P + a.rows_per_split - 1) / a.rows_per_split;
+  return RCDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, the row held in registers (NCH 16-B chunks per lane), exact two-pass.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, f16* __restrict__ y,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const float* __restrict__ pe, int M, int C, int ldx,
+                                                        int ldy, float eps, int rows_per_frame, int frames) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunks = C >> 3;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunks) {
+      Pack16 pk;
+      pk.u = *(const uint4*)(x + (size_t)row * ldx + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = (float)pk.e[e];
+        sum += v[i][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dlt = v[i][e] - mean;
+        sq += dlt * dlt;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  const float* pe_row = pe ? pe + (size_t)((row / rows_per_frame) % frames) * C : nullptr;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunks) {
+      Pack16 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (v[i][e] - mean) * rstd * gamma[c * 8 + e] + beta[c * 8 + e];
+        if (pe_row) f += pe_row[c * 8 + e];
+        o.e[e] = (f16)f;
+      }
+      *(uint4*)(y + (size_t)row * ldy + c * 8) = o.u;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rcdm_groupnorm_workspace_bytes(const rcdm_groupnorm_desc* d) {
+  GnArgs a{};
+  if (!d || gn_plan(d, a)) return 0;
+  return ((size_t)a.samples * a.splits * a.G * 3 + (size_t)a.samples * a.G * 2) * sizeof(float);
+}
+
+int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float* gamma, const float* beta, void* y,
+                        void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!d || !x || !gamma || !beta || !y) return RCDM_EINVAL;
+  GnArgs a{};
+  int rc = gn_plan(d, a);
+  if (rc) return rc;
+  const size_t need = ((size_t)a.samples * a.splits * a.G * 3 + (size_t)a.samples * a.G * 2) * sizeof(float);
+  if (!workspace || workspace_bytes < need) return RCDM_EWORKSPACE;
+  a.x = (const f16*)x; a.y = (f16*)y; a.gamma = gamma; a.beta = beta;
+  a.partial = (float*)workspace;
+  a.stat = a.partial + (size_t)a.samples * a.splits * a.G * 3;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int threads = a.CH * a.RPB;
+  if (threads > 1024) return RCDM_ESHAPE;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.splits, a.samples), dim3(threads), threads * 16 * sizeof(float), stream, a);
+  rc = rcdm_check_launch();
+  if (rc) return rc;
+  const int nsg = a.samples * a.G;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 63) / 64), dim3(64), 0, stream, a);
+  rc = rcdm_check_launch();
+  if (rc) return rc;
+  int bps = (a.P + a.RPB * 8 - 1) / (a.RPB * 8);  // ~8 rows per thread
+  const int cap = (2048 + a.samples - 1) / a.samples;
+  if (bps > cap) bps = cap;
+  if (bps < 1) bps = 1;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(bps, a.samples), dim3(threads), 0, stream, a);
+  return rcdm_check_launch();
+}
+
+int rcdm_layernorm(const rcdm_layernorm_desc* d, const void* x, const float* gamma, const float* beta, const float* pe,
+                   void* y, void* stream_) {
+  if (!d || !x || !gamma || !beta || !y) return RCDM_EINVAL;
+  if (d->M <= 0 || d->C <= 0) return RCDM_EINVAL;
+  if ((d->C & 7) || d->C > 2048 || (d->ldx & 7) || (d->ldy & 7)) return RCDM_ESHAPE;
+  if (pe && (d->rows_per_frame <= 0 || d->frames <= 0)) return RCDM_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nch = ((d->C >> 3) + 63) / 64;
+  dim3 grid((d->M + 3) / 4), block(256);
+  const int rpf = pe ? d->rows_per_frame : 1, fr = pe ? d->frames : 1;
+#define LN_LAUNCH(N)                                                                                       \
+  hipLaunchKernelGGL(layernorm_kernel<N>, grid, block, 0, stream, (const f16*)x, (f16*)y, gamma, beta, pe, \
+                     d->M, d->C, d->ldx, d->ldy, d->eps, rpf, fr)
+  switch (nch) {
+    case 1: LN_LAUNCH(1); break;
+    case 2: LN_LAUNCH(2); break;
+    case 3: LN_LAUNCH(3); break;
+    default: LN_LAUNCH(4); break;
+  }
+#undef LN_LAUNCH
+  return rcdm_check_launch();
+}
+
+}  // extern "C"

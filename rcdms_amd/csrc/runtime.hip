@@ -1,0 +1,76 @@
+// runtime.hip — version, error reporting, hipGraph capture/replay and HIP-event timing for librcdm_hip.so.
+// The reference drives ~10^3 ATen launches per UNet call from Python (src/models/unet.py:322-463);
+// here one denoising step is captured once into a hipGraph and replayed (RCDMs_pipeline.py:480-503 loop).
+#include "common.h"
+
+thread_local int g_rcdm_last_hip_error = 0;
+
+namespace {
+inline int chk(hipError_t e) {
+  if (e != hipSuccess) {
+    g_rcdm_last_hip_error = (int)e;
+    (void)hipGetLastError();
+    return RCDM_ELAUNCH;
+  }
+  return RCDM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rcdm_version(void) { return RCDM_VERSION; }
+int rcdm_last_hip_error(void) { return g_rcdm_last_hip_error; }
+const char* rcdm_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_rcdm_last_hip_error); }
+
+int rcdm_graph_begin_capture(void* stream) {
+  return chk(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+}
+
+int rcdm_graph_end_capture(void* stream, void** graph_exec_out) {
+  if (!graph_exec_out) return RCDM_EINVAL;
+  hipGraph_t graph = nullptr;
+  int rc = chk(hipStreamEndCapture((hipStream_t)stream, &graph));
+  if (rc) return rc;
+  hipGraphExec_t exec = nullptr;
+  rc = chk(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(graph);
+  if (rc) return rc;
+  *graph_exec_out = (void*)exec;
+  return RCDM_OK;
+}
+
+int rcdm_graph_launch(void* graph_exec, void* stream) {
+  if (!graph_exec) return RCDM_EINVAL;
+  return chk(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+}
+
+int rcdm_graph_destroy(void* graph_exec) {
+  if (!graph_exec) return RCDM_OK;
+  return chk(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+}
+
+int rcdm_event_create(void** ev_out) {
+  if (!ev_out) return RCDM_EINVAL;
+  hipEvent_t ev;
+  int rc = chk(hipEventCreate(&ev));
+  if (rc) return rc;
+  *ev_out = (void*)ev;
+  return RCDM_OK;
+}
+int rcdm_event_record(void* ev, void* stream) {
+  if (!ev) return RCDM_EINVAL;
+  return chk(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+}
+int rcdm_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out) {
+  if (!ev_start || !ev_stop || !ms_out) return RCDM_EINVAL;
+  int rc = chk(hipEventSynchronize((hipEvent_t)ev_stop));
+  if (rc) return rc;
+  return chk(hipEventElapsedTime(ms_out, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+}
+int rcdm_event_destroy(void* ev) {
+  if (!ev) return RCDM_OK;
+  return chk(hipEventDestroy((hipEvent_t)ev));
+}
+int rcdm_stream_synchronize(void* stream) { return chk(hipStreamSynchronize((hipStream_t)stream)); }
+
+}  // extern "C"

@@ -1,0 +1,275 @@
+"""ctypes binding of librcdm_hip.so (include/rcdm.h).  Thin: tensors stay owned by torch, only
+`data_ptr()` integers and the current HIP stream handle cross the boundary.  There is NO CPU
+fallback: if the library is missing or a call fails this module raises."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librcdm_hip.so")
+
+EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
+
+_ERR = {-1: "RCDM_EINVAL", -2: "RCDM_ESHAPE", -3: "RCDM_ELAUNCH", -4: "RCDM_EWORKSPACE"}
+
+
+class RcdmError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
+                ("epilogue", C.c_int32), ("rows_per_sample", C.c_int32), ("ldt", C.c_int32),
+                ("out_scale", C.c_float), ("split_k", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n_img", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
+                ("c_in", C.c_int32), ("c_out", C.c_int32), ("stride", C.c_int32),
+                ("upsample", C.c_int32), ("lda", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
+                ("epilogue", C.c_int32), ("rows_per_sample", C.c_int32), ("ldt", C.c_int32),
+                ("out_scale", C.c_float), ("split_k", C.c_int32)]
+
+
+class GroupNormDesc(C.Structure):
+    _fields_ = [("samples", C.c_int32), ("rows_per_sample", C.c_int32), ("C", C.c_int32),
+                ("groups", C.c_int32), ("ldx", C.c_int32), ("ldy", C.c_int32),
+                ("eps", C.c_float), ("silu", C.c_int32)]
+
+
+class LayerNormDesc(C.Structure):
+    _fields_ = [("M", C.c_int32), ("C", C.c_int32), ("ldx", C.c_int32), ("ldy", C.c_int32),
+                ("eps", C.c_float), ("rows_per_frame", C.c_int32), ("frames", C.c_int32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("heads", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
+                ("d", C.c_int32), ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32),
+                ("ldo", C.c_int32), ("scale", C.c_float)]
+
+
+class TemporalAttnDesc(C.Structure):
+    _fields_ = [("samples", C.c_int32), ("frames", C.c_int32), ("pixels", C.c_int32),
+                ("heads", C.c_int32), ("d", C.c_int32), ("ldqkv", C.c_int32), ("ldo", C.c_int32),
+                ("scale", C.c_float)]
+
+
+# every symbol include/rcdm.h declares: name -> (restype, argtypes)
+_P, _I, _F, _SZ = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+SYMBOLS = {
+    "rcdm_version": (C.c_int, []),
+    "rcdm_last_hip_error": (C.c_int, []),
+    "rcdm_last_hip_error_string": (C.c_char_p, []),
+    "rcdm_gemm_workspace_bytes": (_SZ, [C.POINTER(GemmDesc)]),
+    "rcdm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rcdm_conv3x3_workspace_bytes": (_SZ, [C.POINTER(ConvDesc)]),
+    "rcdm_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rcdm_groupnorm_workspace_bytes": (_SZ, [C.POINTER(GroupNormDesc)]),
+    "rcdm_groupnorm_silu": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _SZ, _P]),
+    "rcdm_layernorm": (C.c_int, [C.POINTER(LayerNormDesc), _P, _P, _P, _P, _P, _P]),
+    "rcdm_flash_attn": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
+    "rcdm_temporal_attn": (C.c_int, [C.POINTER(TemporalAttnDesc), _P, _P, _P]),
+    "rcdm_timestep_embed": (C.c_int, [_P, _I, _I, _P, _P]),
+    "rcdm_small_linear": (C.c_int, [_P, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
+    "rcdm_assemble_input": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "rcdm_ncfhw_to_rows": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "rcdm_rows_to_ncfhw": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "rcdm_cfg_ddim_step": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "rcdm_load_timestep": (C.c_int, [_P, _P, _P, _I, _P]),
+    "rcdm_advance_step": (C.c_int, [_P, _P]),
+    "rcdm_pack_f16": (C.c_int, [_P, _P, _SZ, _P]),
+    "rcdm_pack_conv3x3": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "rcdm_pack_geglu_rows": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
+    "rcdm_graph_begin_capture": (C.c_int, [_P]),
+    "rcdm_graph_end_capture": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "rcdm_graph_launch": (C.c_int, [_P, _P]),
+    "rcdm_graph_destroy": (C.c_int, [_P]),
+    "rcdm_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "rcdm_event_record": (C.c_int, [_P, _P]),
+    "rcdm_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    "rcdm_event_destroy": (C.c_int, [_P]),
+    "rcdm_stream_synchronize": (C.c_int, [_P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and type every declared symbol.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RcdmError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `python -m rcdms_amd.build`); "
+            "rcdms_amd has no CPU fallback by design")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        lib = load()
+        extra = ""
+        if rc == -3:
+            extra = f" (hip error {lib.rcdm_last_hip_error()}: {lib.rcdm_last_hip_error_string().decode()})"
+        raise RcdmError(f"{what} failed: {_ERR.get(rc, rc)}{extra}")
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# thin typed wrappers (all enqueue on torch's current stream unless `stream` is given)
+
+def gemm_workspace_bytes(desc):
+    return load().rcdm_gemm_workspace_bytes(C.byref(desc))
+
+
+def gemm(desc, A, W, bias, rowvec, residual, out, ws_ptr=0, ws_bytes=0, stream=None):
+    _check(load().rcdm_gemm(C.byref(desc), A, W, bias, rowvec, residual, out, ws_ptr, ws_bytes,
+                            stream_ptr() if stream is None else stream), "rcdm_gemm")
+
+
+def conv3x3_workspace_bytes(desc):
+    return load().rcdm_conv3x3_workspace_bytes(C.byref(desc))
+
+
+def conv3x3(desc, x, W, bias, rowvec, residual, out, ws_ptr=0, ws_bytes=0, stream=None):
+    _check(load().rcdm_conv3x3(C.byref(desc), x, W, bias, rowvec, residual, out, ws_ptr, ws_bytes,
+                               stream_ptr() if stream is None else stream), "rcdm_conv3x3")
+
+
+def groupnorm_workspace_bytes(desc):
+    return load().rcdm_groupnorm_workspace_bytes(C.byref(desc))
+
+
+def groupnorm_silu(desc, x, gamma, beta, y, ws_ptr, ws_bytes, stream=None):
+    _check(load().rcdm_groupnorm_silu(C.byref(desc), x, gamma, beta, y, ws_ptr, ws_bytes,
+                                      stream_ptr() if stream is None else stream), "rcdm_groupnorm_silu")
+
+
+def layernorm(desc, x, gamma, beta, pe, y, stream=None):
+    _check(load().rcdm_layernorm(C.byref(desc), x, gamma, beta, pe, y,
+                                 stream_ptr() if stream is None else stream), "rcdm_layernorm")
+
+
+def flash_attn(desc, q, k, v, out, stream=None):
+    _check(load().rcdm_flash_attn(C.byref(desc), q, k, v, out,
+                                  stream_ptr() if stream is None else stream), "rcdm_flash_attn")
+
+
+def temporal_attn(desc, qkv, out, stream=None):
+    _check(load().rcdm_temporal_attn(C.byref(desc), qkv, out,
+                                     stream_ptr() if stream is None else stream), "rcdm_temporal_attn")
+
+
+def timestep_embed(t, rows, dim, out, stream=None):
+    _check(load().rcdm_timestep_embed(t, rows, dim, out, stream_ptr() if stream is None else stream),
+           "rcdm_timestep_embed")
+
+
+def small_linear(x, rows, K, W, bias, N, silu_in, silu_out, out, stream=None):
+    _check(load().rcdm_small_linear(x, rows, K, W, bias, N, silu_in, silu_out, out,
+                                    stream_ptr() if stream is None else stream), "rcdm_small_linear")
+
+
+def assemble_input(lat, mask, masked, S, reps, frames, H, W, out, ld, c_pad, stream=None):
+    _check(load().rcdm_assemble_input(lat, mask, masked, S, reps, frames, H, W, out, ld, c_pad,
+                                      stream_ptr() if stream is None else stream), "rcdm_assemble_input")
+
+
+def ncfhw_to_rows(x, b, Cc, frames, H, W, out, ld, c_pad, stream=None):
+    _check(load().rcdm_ncfhw_to_rows(x, b, Cc, frames, H, W, out, ld, c_pad,
+                                     stream_ptr() if stream is None else stream), "rcdm_ncfhw_to_rows")
+
+
+def rows_to_ncfhw(rows, ld, b, Cc, frames, H, W, out, stream=None):
+    _check(load().rcdm_rows_to_ncfhw(rows, ld, b, Cc, frames, H, W, out,
+                                     stream_ptr() if stream is None else stream), "rcdm_rows_to_ncfhw")
+
+
+def cfg_ddim_step(eps, ld, lat, S, reps, frames, H, W, gs, coef, step, stream=None):
+    _check(load().rcdm_cfg_ddim_step(eps, ld, lat, S, reps, frames, H, W, gs, coef, step,
+                                     stream_ptr() if stream is None else stream), "rcdm_cfg_ddim_step")
+
+
+def load_timestep(ts, step, t_out, rows, stream=None):
+    _check(load().rcdm_load_timestep(ts, step, t_out, rows, stream_ptr() if stream is None else stream),
+           "rcdm_load_timestep")
+
+
+def advance_step(step, stream=None):
+    _check(load().rcdm_advance_step(step, stream_ptr() if stream is None else stream), "rcdm_advance_step")
+
+
+def pack_f16(src, dst, n, stream=None):
+    _check(load().rcdm_pack_f16(src, dst, n, stream_ptr() if stream is None else stream), "rcdm_pack_f16")
+
+
+def pack_conv3x3(w, c_out, c_in, cin_pad, dst, stream=None):
+    _check(load().rcdm_pack_conv3x3(w, c_out, c_in, cin_pad, dst, stream_ptr() if stream is None else stream),
+           "rcdm_pack_conv3x3")
+
+
+def pack_geglu_rows(w, bias, n_out, K, w_dst, bias_dst, stream=None):
+    _check(load().rcdm_pack_geglu_rows(w, bias, n_out, K, w_dst, bias_dst,
+                                       stream_ptr() if stream is None else stream), "rcdm_pack_geglu_rows")
+
+
+class Graph:
+    """One captured hipGraph (rcdm_graph_*).  Capture on torch's current stream."""
+
+    def __init__(self):
+        self.exec = C.c_void_p(0)
+        self.stream = None
+
+    def begin(self):
+        self.stream = stream_ptr()
+        _check(load().rcdm_graph_begin_capture(self.stream), "rcdm_graph_begin_capture")
+
+    def end(self):
+        _check(load().rcdm_graph_end_capture(self.stream, C.byref(self.exec)), "rcdm_graph_end_capture")
+
+    def launch(self, stream=None):
+        _check(load().rcdm_graph_launch(self.exec, stream_ptr() if stream is None else stream), "rcdm_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exec and _lib is not None:
+                _lib.rcdm_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.ev = C.c_void_p(0)
+        _check(load().rcdm_event_create(C.byref(self.ev)), "rcdm_event_create")
+
+    def record(self, stream=None):
+        _check(load().rcdm_event_record(self.ev, stream_ptr() if stream is None else stream), "rcdm_event_record")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float(0)
+        _check(load().rcdm_event_elapsed_ms(self.ev, stop.ev, C.byref(ms)), "rcdm_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.ev and _lib is not None:
+                _lib.rcdm_event_destroy(self.ev)
+        except Exception:
+            pass

@@ -1,0 +1,370 @@
+"""GPU parity tests, kernel level: every C-ABI entry point of librcdm_hip.so against the oracle's op
+(oracle/unet_oracle.py, CPU fp32) on the same seeded inputs.  Inputs are rounded to f16 first so the
+only differences are accumulation order and the single output rounding.
+
+Tolerance (stated once): outputs are f16 -> relative 2^-10 per rounding; we accept
+|hip - oracle| <= 4e-3 * max|oracle| + 2e-3 * |oracle| elementwise unless a test says otherwise."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def close(got, ref, rel=2e-3, abs_frac=4e-3):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), "non-finite output"
+    tol = abs_frac * ref.abs().max() + rel * ref.abs()
+    err = (got - ref).abs()
+    bad = err > tol
+    assert not bad.any(), f"max err {err.max():.4g} (ref max {ref.abs().max():.4g}), {int(bad.sum())} / {bad.numel()} outside tol"
+
+
+def h16(x):
+    return x.half().float()
+
+
+def rows_from_5d(x5, ld=None, dev=DEV):
+    """(b,C,f,H,W) fp32 -> f16 rows [b*f*H*W][ld] on the GPU."""
+    b, c, f, h, w = x5.shape
+    r = x5.permute(0, 2, 3, 4, 1).reshape(b * f * h * w, c).half()
+    ld = ld or c
+    out = torch.zeros(r.shape[0], ld, dtype=torch.float16)
+    out[:, :c] = r
+    return out.to(dev)
+
+
+def rows_to_5d(rows, b, c, f, h, w):
+    return rows[:, :c].float().cpu().reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3)
+
+
+def ws(nbytes):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,epi,split", [
+    (256, 128, 64, 0, 1),
+    (300, 320, 320, 1 | 4, 1),       # M tail, N tail, bias + residual
+    (300, 320, 320, 1 | 2, 1),       # bias + per-sample row vector
+    (640, 1280, 1280, 1, 0),         # heuristic split-K
+    (130, 72, 200, 1 | 4, 3),        # forced split-K, K tail (200 = 3*64 + 8), N % 128 != 0
+    (1024, 960, 320, 0, 1),
+])
+def test_gemm(hiplib, M, N, K, epi, split):
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(1234 + M + N + K)
+    A = h16(torch.randn(M, K, generator=g))
+    W = h16(torch.randn(N, K, generator=g) * K ** -0.5)
+    bias = torch.randn(N, generator=g)
+    rps = 100
+    nsamp = (M + rps - 1) // rps
+    rowvec = torch.randn(nsamp, N, generator=g)
+    res = h16(torch.randn(M, N, generator=g))
+    ref = A @ W.t()
+    if epi & 1:
+        ref = ref + bias
+    if epi & 2:
+        ref = ref + rowvec[torch.arange(M) // rps]
+    if epi & 4:
+        ref = ref + res
+    lda, ldc, ldr = K + 8, N + 16, N + 8
+    Ad = torch.zeros(M, lda, dtype=torch.float16); Ad[:, :K] = A.half(); Ad = Ad.to(DEV)
+    Rd = torch.zeros(M, ldr, dtype=torch.float16); Rd[:, :N] = res.half(); Rd = Rd.to(DEV)
+    Wd, bd, rvd = W.half().to(DEV), bias.to(DEV), rowvec.to(DEV)
+    out = torch.full((M, ldc), float("nan"), dtype=torch.float16, device=DEV)
+    d = hip.GemmDesc(M, N, K, lda, ldc, ldr, epi, rps, N, 1.0, split)
+    w = ws(hip.gemm_workspace_bytes(d))
+    hip.gemm(d, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), rvd.data_ptr(), Rd.data_ptr(), out.data_ptr(),
+             w.data_ptr(), w.numel())
+    torch.cuda.synchronize()
+    close(out[:, :N], ref)
+    assert torch.isnan(out[:, N:].float()).all(), "wrote outside the N columns"
+
+
+def test_gemm_transpose_detecting(hiplib):
+    """A = I (padded) with an ASYMMETRIC W catches a row/col swap in the MFMA C layout."""
+    from rcdms_amd import hip
+    M = N = K = 128
+    A = torch.eye(M, K)
+    W = (torch.arange(N)[:, None] * 0.01 + torch.arange(K)[None, :] * 0.37) % 3.0
+    W = h16(W)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    d = hip.GemmDesc(M, N, K, K, N, N, 0, 1, 0, 1.0, 1)
+    hip.gemm(d, A.half().to(DEV).data_ptr(), W.half().to(DEV).data_ptr(), 0, 0, 0, out.data_ptr(), 0, 0)
+    torch.cuda.synchronize()
+    close(out, W.t(), rel=1e-3, abs_frac=1e-3)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+def test_gemm_geglu(hiplib, split):
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(7)
+    M, C = 200, 64
+    x = h16(torch.randn(M, C, generator=g))
+    sd = {"ff.net.0.proj.weight": h16(torch.randn(8 * C, C, generator=g) * C ** -0.5),
+          "ff.net.0.proj.bias": torch.randn(8 * C, generator=g) * 0.1}
+    hg = F.linear(x, sd["ff.net.0.proj.weight"], sd["ff.net.0.proj.bias"])
+    hidden, gate = hg.chunk(2, dim=-1)
+    ref = hidden * F.gelu(gate)
+    wp = torch.empty(8 * C, C, dtype=torch.float16, device=DEV)
+    bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+    hip.pack_geglu_rows(sd["ff.net.0.proj.weight"].to(DEV).data_ptr(), sd["ff.net.0.proj.bias"].to(DEV).data_ptr(),
+                        8 * C, C, wp.data_ptr(), bp.data_ptr())
+    out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
+    d = hip.GemmDesc(M, 8 * C, C, C, 4 * C, 0, hip.EPI_BIAS | hip.EPI_GEGLU, 1, 0, 1.0, split)
+    w = ws(hip.gemm_workspace_bytes(d))
+    hip.gemm(d, x.half().to(DEV).data_ptr(), wp.data_ptr(), bp.data_ptr(), 0, 0, out.data_ptr(), w.data_ptr(), w.numel())
+    torch.cuda.synchronize()
+    close(out, ref)
+
+
+@pytest.mark.parametrize("b,f,H,W,cin,cout,stride,up,split", [
+    (1, 2, 8, 8, 64, 128, 1, 0, 1),
+    (2, 3, 10, 6, 72, 72, 1, 0, 1),     # ragged: c_in tail, N tail, M tail
+    (1, 5, 16, 16, 64, 64, 2, 0, 1),    # Downsample3D
+    (1, 5, 8, 8, 128, 64, 1, 1, 1),     # Upsample3D folded into the conv
+    (2, 1, 8, 8, 320, 320, 1, 0, 4),    # split-K
+])
+def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split):
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(99 + cin + cout + stride + up)
+    x = h16(torch.randn(b, cin, f, H, W, generator=g))
+    w = h16(torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=g)
+    temb = torch.randn(b, cout, generator=g)
+    xin = F.interpolate(x, scale_factor=[1.0, 2.0, 2.0], mode="nearest") if up else x
+    ref = O.conv_frames(xin, w, bias, stride=stride, padding=1) + temb[:, :, None, None, None]
+    Ho, Wo = ref.shape[-2:]
+    res = h16(torch.randn(ref.shape, generator=g))
+    ref = ref + res
+    lda = cin + 8
+    xd = rows_from_5d(x, lda)
+    rd = rows_from_5d(res)
+    wp = torch.empty(cout, 9 * cin, dtype=torch.float16, device=DEV)
+    hip.pack_conv3x3(w.to(DEV).data_ptr(), cout, cin, cin, wp.data_ptr())
+    out = torch.empty(b * f * Ho * Wo, cout, dtype=torch.float16, device=DEV)
+    d = hip.ConvDesc(b * f, H, W, cin, cout, stride, up, lda, cout, cout,
+                     hip.EPI_BIAS | hip.EPI_ROWVEC | hip.EPI_RESIDUAL, f * Ho * Wo, cout, 1.0, split)
+    wsb = ws(hip.conv3x3_workspace_bytes(d))
+    bd, td = bias.to(DEV), temb.to(DEV)
+    hip.conv3x3(d, xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), td.data_ptr(), rd.data_ptr(), out.data_ptr(),
+                wsb.data_ptr(), wsb.numel())
+    torch.cuda.synchronize()
+    close(rows_to_5d(out, b, cout, f, Ho, Wo), ref)
+
+
+@pytest.mark.parametrize("b,f,H,W,C,cross,silu", [
+    (2, 5, 8, 8, 320, True, True),      # resnet norm: statistics across the 5 frames
+    (2, 5, 8, 8, 320, False, False),    # transformer / motion-module norm: per frame, eps 1e-6
+    (1, 5, 16, 16, 64, True, True),     # cg = 2 (tiny config)
+    (2, 3, 4, 4, 2560, True, True),     # widest concat input
+    (1, 2, 6, 10, 960, False, True),
+])
+def test_groupnorm(hiplib, b, f, H, W, C, cross, silu):
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(5 + C)
+    x = h16(torch.randn(b, C, f, H, W, generator=g) * 2.0 + 0.7)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    eps = 1e-5 if cross else 1e-6
+    if cross:
+        ref = O.group_norm_cross_frame(x, gamma, beta, 32, eps)
+    else:
+        x4 = x.permute(0, 2, 1, 3, 4).reshape(b * f, C, H, W)
+        ref = O.group_norm_per_frame(x4, gamma, beta, 32, eps).reshape(b, f, C, H, W).permute(0, 2, 1, 3, 4)
+    if silu:
+        ref = F.silu(ref)
+    ldx = C + 8
+    xd = rows_from_5d(x, ldx)
+    y = torch.empty(b * f * H * W, C, dtype=torch.float16, device=DEV)
+    samples, rps = (b, f * H * W) if cross else (b * f, H * W)
+    d = hip.GroupNormDesc(samples, rps, C, 32, ldx, C, eps, int(silu))
+    w = ws(hip.groupnorm_workspace_bytes(d))
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    hip.groupnorm_silu(d, xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), y.data_ptr(), w.data_ptr(), w.numel())
+    torch.cuda.synchronize()
+    close(rows_to_5d(y, b, C, f, H, W), ref)
+
+
+@pytest.mark.parametrize("M,C,pe", [(50, 320, False), (40, 640, True), (7, 1280, True), (33, 64, False)])
+def test_layernorm(hiplib, M, C, pe):
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(11 + C)
+    frames, rpf = 5, 4
+    if pe:
+        M = 2 * frames * rpf
+    x = h16(torch.randn(M, C, generator=g) * 3 + 1)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    table = O.sinusoid_table(C, frames)
+    if pe:
+        ref = ref + table[(torch.arange(M) // rpf) % frames]
+    xd = x.half().to(DEV)
+    y = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    d = hip.LayerNormDesc(M, C, C, C, 1e-5, rpf, frames)
+    gd, bd, td = gamma.to(DEV), beta.to(DEV), table.to(DEV)
+    hip.layernorm(d, xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), td.data_ptr() if pe else 0, y.data_ptr())
+    torch.cuda.synchronize()
+    close(y, ref)
+
+
+@pytest.mark.parametrize("batch,heads,Lq,Lk,d", [
+    (2, 8, 256, 256, 40),    # self-attention, 64x64-latent head dim
+    (2, 8, 200, 85, 40),     # cross-attention over 85 context rows (ragged key tile, ragged query tile)
+    (3, 8, 64, 91, 80),
+    (1, 8, 130, 130, 160),
+    (2, 8, 16, 16, 160),     # 256x256 image mid block: 4x4 latent patches
+    (2, 4, 96, 85, 8),       # tiny-config head dims
+    (1, 2, 70, 64, 16),
+    (1, 2, 64, 70, 32),
+])
+def test_flash_attn(hiplib, batch, heads, Lq, Lk, d):
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(3 + Lq + Lk + d)
+    C = heads * d
+    q = h16(torch.randn(batch, Lq, C, generator=g))
+    k = h16(torch.randn(batch, Lk, C, generator=g))
+    v = h16(torch.randn(batch, Lk, C, generator=g))
+    ref = O.attention_core(q, k, v, heads)
+    # q inside a fused [q|k|v]-style wider buffer, k/v interleaved in one [k|v] buffer
+    qd = torch.zeros(batch * Lq, 3 * C, dtype=torch.float16); qd[:, :C] = q.reshape(-1, C).half(); qd = qd.to(DEV)
+    kv = torch.cat([k.reshape(-1, C), v.reshape(-1, C)], dim=1).half().to(DEV)
+    out = torch.empty(batch * Lq, C, dtype=torch.float16, device=DEV)
+    desc = hip.AttnDesc(batch, heads, Lq, Lk, d, 3 * C, 2 * C, 2 * C, C, d ** -0.5)
+    hip.flash_attn(desc, qd.data_ptr(), kv.data_ptr(), kv.data_ptr() + 2 * C, out.data_ptr())
+    torch.cuda.synchronize()
+    close(out.reshape(batch, Lq, C), ref)
+
+
+def test_flash_attn_forced_rescale(hiplib):
+    """A key in a LATE tile that dominates one query's scores forces the online-softmax rescale branch."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(21)
+    heads, d, L = 2, 40, 256
+    C = heads * d
+    q = h16(torch.randn(1, L, C, generator=g))
+    k = h16(torch.randn(1, L, C, generator=g))
+    v = h16(torch.randn(1, L, C, generator=g))
+    k[0, 200, :d] = h16(q[0, 17, :d] * 4.0)      # spike in the 4th key tile for query 17 / head 0
+    ref = O.attention_core(q, k, v, heads)
+    qd, kd, vd = (t.reshape(-1, C).half().to(DEV) for t in (q, k, v))
+    out = torch.empty(L, C, dtype=torch.float16, device=DEV)
+    desc = hip.AttnDesc(1, heads, L, L, d, C, C, C, C, d ** -0.5)
+    hip.flash_attn(desc, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    close(out.reshape(1, L, C), ref)
+
+
+@pytest.mark.parametrize("b,frames,pixels,heads,d", [(2, 5, 64, 8, 40), (1, 5, 16, 8, 160), (2, 5, 33, 8, 8), (1, 3, 20, 4, 16)])
+def test_temporal_attn(hiplib, b, frames, pixels, heads, d):
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(17 + pixels + d)
+    C = heads * d
+    qkv = h16(torch.randn(b * frames * pixels, 3 * C, generator=g))
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+
+    def regroup(x):  # "(b f) d c -> (b d) f c"  motion_module.py:299
+        return x.reshape(b, frames, pixels, C).permute(0, 2, 1, 3).reshape(b * pixels, frames, C)
+
+    o = O.attention_core(regroup(q), regroup(k), regroup(v), heads)
+    ref = o.reshape(b, pixels, frames, C).permute(0, 2, 1, 3).reshape(b * frames * pixels, C)
+    out = torch.empty(b * frames * pixels, C, dtype=torch.float16, device=DEV)
+    desc = hip.TemporalAttnDesc(b, frames, pixels, heads, d, 3 * C, C, d ** -0.5)
+    hip.temporal_attn(desc, qkv.half().to(DEV).data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    close(out, ref)
+
+
+def test_timestep_embed_and_small_linear(hiplib):
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(2)
+    t = torch.tensor([981.0, 981.0, 1.0])
+    ref = O.timestep_embedding(t, 320)
+    out = torch.empty(3, 320, device=DEV)
+    hip.timestep_embed(t.to(DEV).data_ptr(), 3, 320, out.data_ptr())
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 2e-4
+    W1 = h16(torch.randn(1280, 320, generator=g) * 0.05)
+    b1 = torch.randn(1280, generator=g)
+    ref2 = F.silu(F.linear(ref, W1, b1))
+    o2 = torch.empty(3, 1280, device=DEV)
+    hip.small_linear(out.data_ptr(), 3, 320, W1.half().to(DEV).data_ptr(), b1.to(DEV).data_ptr(), 1280, 0, 1, o2.data_ptr())
+    W2 = h16(torch.randn(200, 1280, generator=g) * 0.03)
+    ref3 = F.linear(F.silu(ref2), W2)
+    o3 = torch.empty(3, 200, device=DEV)
+    hip.small_linear(o2.data_ptr(), 3, 1280, W2.half().to(DEV).data_ptr(), 0, 200, 1, 0, o3.data_ptr())
+    torch.cuda.synchronize()
+    close(o2, ref2, rel=1e-3, abs_frac=1e-3)
+    close(o3, ref3, rel=1e-3, abs_frac=1e-3)
+
+
+def test_layout_and_ddim(hiplib):
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(8)
+    S, f, H, W = 2, 5, 8, 8
+    lat = torch.randn(S, 4, f, H, W, generator=g)
+    mask = (torch.rand(2 * S, 1, f, H, W, generator=g) > 0.5).float()
+    masked = torch.randn(2 * S, 4, f, H, W, generator=g)
+    ref_in = torch.cat([torch.cat([lat] * 2), mask, masked], dim=1)       # RCDMs_pipeline.py:482-486
+    rows = torch.full((2 * S * f * H * W, 64), float("nan"), dtype=torch.float16, device=DEV)
+    hip.assemble_input(lat.to(DEV).data_ptr(), mask.to(DEV).data_ptr(), masked.to(DEV).data_ptr(), S, 2, f, H, W,
+                       rows.data_ptr(), 64, 64)
+    torch.cuda.synchronize()
+    close(rows_to_5d(rows, 2 * S, 9, f, H, W), ref_in, rel=1e-3, abs_frac=1e-3)
+    assert (rows[:, 9:] == 0).all()
+    # generic converters round-trip
+    x = torch.randn(3, 9, f, H, W, generator=g)
+    r2 = torch.empty(3 * f * H * W, 16, dtype=torch.float16, device=DEV)
+    hip.ncfhw_to_rows(x.to(DEV).data_ptr(), 3, 9, f, H, W, r2.data_ptr(), 16, 16)
+    back = torch.empty(3, 9, f, H, W, device=DEV)
+    hip.rows_to_ncfhw(r2.data_ptr(), 16, 3, 9, f, H, W, back.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), x.half().float())
+    # CFG + DDIM step against the oracle scheduler
+    sched = O.DDIMOracle(); sched.set_timesteps(20)
+    eps = h16(torch.randn(2 * S, 4, f, H, W, generator=g))
+    eps_rows = rows_from_5d(eps, 32)
+    gs = 2.0
+    coef = []
+    for t in sched.timesteps:
+        pt = int(t) - 1000 // 20
+        a_t = sched.alphas_cumprod[int(t)]; a_p = sched.alphas_cumprod[pt] if pt >= 0 else torch.tensor(1.0)
+        coef.append([a_t.sqrt(), (1 - a_t).sqrt(), a_p.sqrt(), (1 - a_p).sqrt()])
+    coef = torch.tensor(coef, dtype=torch.float32).to(DEV)
+    step = torch.tensor([3], dtype=torch.int32, device=DEV)
+    lat_d = lat.clone().to(DEV)
+    hip.cfg_ddim_step(eps_rows.data_ptr(), 32, lat_d.data_ptr(), S, 2, f, H, W, gs, coef.data_ptr(), step.data_ptr())
+    hip.advance_step(step.data_ptr())
+    torch.cuda.synchronize()
+    e_u, e_c = eps.chunk(2)
+    ref = sched.step(e_u + gs * (e_c - e_u), sched.timesteps[3], lat)
+    assert (lat_d.cpu() - ref).abs().max() < 1e-5
+    assert int(step.item()) == 4
+
+
+def test_graph_capture_replay(hiplib):
+    from rcdms_amd import hip
+    M = N = K = 128
+    A = torch.randn(M, K).half().to(DEV)
+    W = torch.randn(N, K).half().to(DEV)
+    out = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+    d = hip.GemmDesc(M, N, K, K, N, N, 0, 1, 0, 1.0, 1)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        gr = hip.Graph()
+        gr.begin()
+        hip.gemm(d, A.data_ptr(), W.data_ptr(), 0, 0, 0, out.data_ptr(), 0, 0)
+        gr.end()
+        assert float(out.abs().sum()) == 0.0, "capture must not execute"
+        gr.launch()
+        s.synchronize()
+    close(out, A.float().cpu() @ W.float().cpu().t())
