@@ -1,0 +1,143 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Mint the golden vectors under tests/golden/ by running the
+REFERENCE's own model classes (imported from /root/reference through oracle/ref_scaffold.py) on CPU fp32
+with procedural name-seeded weights (rcdms_amd/synth.py).  Run in the build container only:
+
+    python -m oracle.make_golden [--full]      # --full adds the full-width UNet at 32x32 and 64x64 latents
+
+What is stored: small inputs and the reference outputs (fp32 .npz), plus a digest of the reference's
+state-dict key/shape list so the mirrored classes are checked to have the identical 1286-key layout.
+Weights are NOT stored: both sides regenerate them from the parameter names."""
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_scaffold  # noqa: E402
+from rcdms_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def key_digest(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(f"{k}:{tuple(sd[k].shape)};".encode())
+    return h.hexdigest()
+
+
+def load_procedural(module, seed):
+    sd = module.state_dict()
+    new = synth.procedural_state_dict({k: v.shape for k, v in sd.items()}, seed)
+    module.load_state_dict(new)
+    return key_digest(sd)
+
+
+def randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    out = {}
+    for k, v in arrays.items():
+        out[k] = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez(path, **out)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+@torch.no_grad()
+def blocks():
+    ref_scaffold.load_reference_models()
+    import refsrc.models.attention as r_att
+    import refsrc.models.motion_module as r_mm
+    import refsrc.models.resnet as r_res
+
+    # ResnetBlock3D, Cin != Cout (1x1 shortcut) and Cin == Cout — cross-frame GroupNorm (F2)
+    for tag, cin, cout in (("resnet_64_128", 64, 128), ("resnet_64_64", 64, 64)):
+        m = r_res.ResnetBlock3D(in_channels=cin, out_channels=cout, temb_channels=256, eps=1e-5, groups=32,
+                                non_linearity="silu", use_inflated_groupnorm=False).eval()
+        dig = load_procedural(m, seed=1)
+        x, temb = randn((2, cin, 5, 8, 8), 10), randn((2, 256), 11)
+        save(tag, x=x, temb=temb, y=m(x, temb), digest=dig)
+
+    # Transformer3DModel: 8 heads x 8, context 13 tokens x 64
+    m = r_att.Transformer3DModel(8, 8, in_channels=64, num_layers=1, cross_attention_dim=64, norm_num_groups=32,
+                                 use_linear_projection=False, upcast_attention=False,
+                                 unet_use_cross_frame_attention=False, unet_use_temporal_attention=False).eval()
+    dig = load_procedural(m, seed=2)
+    x, ctx = randn((2, 64, 5, 8, 8), 20), randn((10, 13, 64), 21)
+    save("transformer_64", x=x, ctx=ctx, y=m(x, encoder_hidden_states=ctx).sample, digest=dig)
+
+    # VanillaTemporalModule (weights procedural, so the zero-initialised proj_out is NOT zero here)
+    m = r_mm.VanillaTemporalModule(in_channels=64, **ref_scaffold.TESTING_YAML_UNET_KWARGS["motion_module_kwargs"]).eval()
+    dig = load_procedural(m, seed=3)
+    x = randn((2, 64, 5, 8, 8), 30)
+    save("motion_64", x=x, y=m(x, None, None), digest=dig)
+
+    # samplers
+    m = r_res.Downsample3D(64, use_conv=True, out_channels=64, padding=1, name="op").eval()
+    dig = load_procedural(m, seed=4)
+    x = randn((2, 64, 5, 8, 8), 40)
+    save("downsample_64", x=x, y=m(x), digest=dig)
+    m = r_res.Upsample3D(64, use_conv=True, out_channels=64).eval()
+    dig = load_procedural(m, seed=5)
+    save("upsample_64", x=x, y=m(x), digest=dig)
+    m = r_res.InflatedConv3d(9, 64, kernel_size=3, padding=(1, 1)).eval()
+    dig = load_procedural(m, seed=6)
+    x9 = randn((2, 9, 5, 8, 8), 41)
+    save("conv_in_9_64", x=x9, y=m(x9), digest=dig)
+
+
+@torch.no_grad()
+def tiny_unet():
+    """Full stage-2 topology at width 64 (layers_per_block 2): 16x16 and 32x32 latents."""
+    m = ref_scaffold.build_reference_unet(width=64, cross_dim=64)
+    dig = load_procedural(m, seed=7)
+    print("  tiny UNet params: %.1f M, keys %d" % (sum(p.numel() for p in m.parameters()) / 1e6, len(m.state_dict())))
+    for hw, t in ((16, 981), (32, 441)):
+        x, ctx = randn((2, 9, 5, hw, hw), 50 + hw), randn((10, 13, 64), 51 + hw)
+        y = m(x, torch.tensor(t), encoder_hidden_states=ctx, return_dict=False)[0]
+        save(f"unet_tiny_{hw}", x=x, ctx=ctx, t=np.int64(t), y=y, digest=dig)
+    # per-batch timesteps tensor + return_dict=True path returns the raw tensor (unet.py:462)
+    x, ctx = randn((2, 9, 5, 16, 16), 60), randn((10, 13, 64), 61)
+    y = m(x, torch.tensor([981, 1]), ctx)
+    assert torch.is_tensor(y)
+    save("unet_tiny_16_tvec", x=x, ctx=ctx, t=np.array([981, 1], dtype=np.int64), y=y, digest=dig)
+
+
+@torch.no_grad()
+def full_unet():
+    """Full-width (1276.9 M parameter) reference UNet on the synthetic story of SURVEY §8(d): outputs only."""
+    t0 = time.time()
+    m = ref_scaffold.build_reference_unet()
+    dig = load_procedural(m, seed=0)
+    print("  full UNet built + procedural weights in %.0f s; keys %d" % (time.time() - t0, len(m.state_dict())))
+    for hw, t in ((32, 951), (64, 981)):
+        s = synth.synthetic_story(stories=1, latent_hw=(hw, hw), ctx_len=85, seed=42)
+        x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1)
+        t0 = time.time()
+        y = m(x, torch.tensor(t), encoder_hidden_states=s["ctx"], return_dict=False)[0]
+        print("  reference forward %dx%d: %.1f s" % (hw, hw, time.time() - t0))
+        save(f"unet_full_{hw}", t=np.int64(t), y=y, digest=dig)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    if a.only in ("", "blocks"):
+        print("blocks"); blocks()
+    if a.only in ("", "tiny"):
+        print("tiny UNet"); tiny_unet()
+    if a.full or a.only == "full":
+        print("full UNet"); full_unet()

@@ -1,0 +1,784 @@
+"""Host-side launch planner for the stage-2 denoiser on MI355X.
+
+Turns the reference's module graph (UNet3DConditionModel.forward, src/models/unet.py:322-463 and the
+block wiring of src/models/unet_blocks.py) into a flat, static list of librcdm_hip.so launches over
+pre-allocated HBM buffers, so that one denoising step can be captured once into a hipGraph and
+replayed (RCDMs_pipeline.py:480-503 calls it T times per story).
+
+Data layout in HBM: every activation is channels-last f16 rows
+X[(b f y x)][C] with an explicit row stride, so
+  * every einops permute / .contiguous() of the reference is index arithmetic, and
+  * torch.cat([h, skip], dim=1) (unet_blocks.py:644,754) is free: each skip tensor is WRITTEN by its
+    producer straight into the right-hand columns of the concat buffer its consumer will read.
+Weights are repacked once to f16 kernel layouts (fused [q;k;v], [k;v], GEGLU row interleave,
+conv3x3 tap-major); cross-attention K/V of the context are computed once per context, not per step.
+
+torch is used only for device memory, streams and host<->device copies.
+"""
+import math
+
+import torch
+
+from . import hip
+
+
+class Buf:
+    """A device buffer whose size is the max over all requests made while planning."""
+    __slots__ = ("name", "nbytes", "t")
+
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes, self.t = name, int(nbytes), None
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+class Rows:
+    """View of f16 rows [M][C] with row stride ld (elements) inside a Buf at element offset off."""
+    __slots__ = ("buf", "off", "M", "C", "ld")
+
+    def __init__(self, buf, off, M, C, ld):
+        self.buf, self.off, self.M, self.C, self.ld = buf, int(off), int(M), int(C), int(ld)
+
+    @property
+    def ptr(self):
+        return self.buf.t.data_ptr() + 2 * self.off
+
+    def cols(self, c0, c):
+        return Rows(self.buf, self.off + c0, self.M, c, self.ld)
+
+
+class Plan:
+    """Ordered launch list + the buffers it touches."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.bufs = {}
+        self.ops = []
+        self.keep = []  # tensors that must outlive the plan (packed weights etc.)
+        self.n_launch = 0
+
+    def scratch(self, name, nbytes):
+        b = self.bufs.get(name)
+        if b is None:
+            b = self.bufs[name] = Buf(name, nbytes)
+        elif nbytes > b.nbytes:
+            assert b.t is None, "scratch grown after materialize"
+            b.nbytes = int(nbytes)
+        return b
+
+    def new(self, name, nbytes):
+        assert name not in self.bufs, name
+        b = self.bufs[name] = Buf(name, nbytes)
+        return b
+
+    def rows(self, name, M, C, ld=None, unique=False):
+        ld = ld or C
+        buf = (self.new if unique else self.scratch)(name, M * ld * 2)
+        return Rows(buf, 0, M, C, ld)
+
+    def materialize(self):
+        for b in self.bufs.values():
+            if b.t is None:
+                b.t = torch.zeros(max(b.nbytes, 256), dtype=torch.uint8, device=self.device)
+
+    def total_bytes(self):
+        return sum(b.nbytes for b in self.bufs.values())
+
+    def add(self, fn):
+        self.ops.append(fn)
+
+    def run(self, ops=None):
+        for op in (self.ops if ops is None else ops):
+            op()
+
+
+# ------------------------------------------------------------------------------------------------
+# single-kernel emitters
+
+def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geglu=False, scale=1.0, split_k=0):
+    """out[M][N or N/2] = epi(A[M][K] W[N][K]^T); rowvec = (tensor, elem_offset, ldt, rows_per_sample)."""
+    epi = 0
+    if bias is not None:
+        epi |= hip.EPI_BIAS
+    if rowvec is not None:
+        epi |= hip.EPI_ROWVEC
+    if residual is not None:
+        epi |= hip.EPI_RESIDUAL
+    if geglu:
+        epi |= hip.EPI_GEGLU
+    d = hip.GemmDesc(A.M, N, K, A.ld, out.ld, residual.ld if residual is not None else 0, epi,
+                     rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k)
+    wsb = hip.gemm_workspace_bytes(d)
+    ws = plan.scratch("splitk_ws", max(wsb, 256))
+    bptr = bias.data_ptr() if bias is not None else 0
+    rv_t, rv_off = (rowvec[0], rowvec[1]) if rowvec else (None, 0)
+
+    def op():
+        hip.gemm(d, A.ptr, Wt.data_ptr(), bptr, (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0,
+                 residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
+    plan.add(op)
+    plan.keep += [Wt, bias, rv_t]
+    plan.n_launch += 2 if wsb else 1
+
+
+def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=None, rowvec=None, residual=None,
+                 scale=1.0, split_k=0):
+    epi = 0
+    if bias is not None:
+        epi |= hip.EPI_BIAS
+    if rowvec is not None:
+        epi |= hip.EPI_ROWVEC
+    if residual is not None:
+        epi |= hip.EPI_RESIDUAL
+    d = hip.ConvDesc(n_img, H, W, cin, cout, stride, up, x.ld, out.ld, residual.ld if residual is not None else 0,
+                     epi, rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k)
+    wsb = hip.conv3x3_workspace_bytes(d)
+    ws = plan.scratch("splitk_ws", max(wsb, 256))
+    bptr = bias.data_ptr() if bias is not None else 0
+    rv_t, rv_off = (rowvec[0], rowvec[1]) if rowvec else (None, 0)
+
+    def op():
+        hip.conv3x3(d, x.ptr, Wt.data_ptr(), bptr, (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0,
+                    residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
+    plan.add(op)
+    plan.keep += [Wt, bias, rv_t]
+    plan.n_launch += 2 if wsb else 1
+
+
+def emit_groupnorm(plan, x, samples, rows_per_sample, gamma, beta, eps, silu, out, groups=32):
+    d = hip.GroupNormDesc(samples, rows_per_sample, x.C, groups, x.ld, out.ld, eps, int(silu))
+    ws = plan.scratch("gn_ws", hip.groupnorm_workspace_bytes(d))
+
+    def op():
+        hip.groupnorm_silu(d, x.ptr, gamma.data_ptr(), beta.data_ptr(), out.ptr, ws.ptr, ws.nbytes)
+    plan.add(op)
+    plan.keep += [gamma, beta]
+    plan.n_launch += 3
+
+
+def emit_layernorm(plan, x, gamma, beta, out, pe=None, rows_per_frame=1, frames=1):
+    d = hip.LayerNormDesc(x.M, x.C, x.ld, out.ld, 1e-5, rows_per_frame, frames)
+
+    def op():
+        hip.layernorm(d, x.ptr, gamma.data_ptr(), beta.data_ptr(), pe.data_ptr() if pe is not None else 0, out.ptr)
+    plan.add(op)
+    plan.keep += [gamma, beta, pe]
+    plan.n_launch += 1
+
+
+def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out):
+    d = hip.AttnDesc(batch, heads, Lq, Lk, d_head, q.ld, k.ld, v.ld, out.ld, d_head ** -0.5)
+
+    def op():
+        hip.flash_attn(d, q.ptr, k.ptr, v.ptr, out.ptr)
+    plan.add(op)
+    plan.n_launch += 1
+
+
+def emit_temporal_attn(plan, qkv, samples, frames, pixels, heads, d_head, out):
+    d = hip.TemporalAttnDesc(samples, frames, pixels, heads, d_head, qkv.ld, out.ld, d_head ** -0.5)
+
+    def op():
+        hip.temporal_attn(d, qkv.ptr, out.ptr)
+    plan.add(op)
+    plan.n_launch += 1
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing (fp32 reference layout -> f16 kernel layout), once
+
+class Packer:
+    def __init__(self, sd, device):
+        self.sd, self.device = sd, torch.device(device)
+        self._tmp = []
+
+    def f32(self, key):
+        t = self.sd[key].detach().to(self.device, torch.float32).contiguous()
+        return t
+
+    def has(self, key):
+        return key in self.sd
+
+    def vec(self, key):
+        return self.f32(key)
+
+    def mat_f16(self, *keys):
+        """rows of several [n_i][K] matrices stacked -> f16 [sum n_i][K]"""
+        src = torch.cat([self.f32(k).reshape(self.sd[k].shape[0], -1) for k in keys], dim=0).contiguous()
+        dst = torch.empty(src.shape, dtype=torch.float16, device=self.device)
+        hip.pack_f16(src.data_ptr(), dst.data_ptr(), src.numel())
+        self._tmp.append(src)
+        return dst
+
+    def conv3x3(self, key, cin_pad=None, cout_pad=None):
+        w = self.f32(key)
+        cout, cin = w.shape[0], w.shape[1]
+        cin_pad = cin_pad or cin
+        if cout_pad and cout_pad > cout:
+            w = torch.cat([w, torch.zeros(cout_pad - cout, cin, 3, 3, device=self.device)], dim=0).contiguous()
+            cout = cout_pad
+        dst = torch.empty(cout, 9 * cin_pad, dtype=torch.float16, device=self.device)
+        hip.pack_conv3x3(w.data_ptr(), cout, cin, cin_pad, dst.data_ptr())
+        self._tmp.append(w)
+        return dst
+
+    def geglu(self, wkey, bkey):
+        w, b = self.f32(wkey), self.f32(bkey)
+        n_out, K = w.shape
+        wd = torch.empty(n_out, K, dtype=torch.float16, device=self.device)
+        bd = torch.empty(n_out, dtype=torch.float32, device=self.device)
+        hip.pack_geglu_rows(w.data_ptr(), b.data_ptr(), n_out, K, wd.data_ptr(), bd.data_ptr())
+        self._tmp += [w, b]
+        return wd, bd
+
+    def done(self):
+        torch.cuda.synchronize(self.device)
+        self._tmp.clear()
+
+
+class _NS:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def pack_resnet(pk, p):
+    w = _NS(cin=pk.sd[p + "conv1.weight"].shape[1], cout=pk.sd[p + "conv1.weight"].shape[0])
+    w.g1, w.b1 = pk.vec(p + "norm1.weight"), pk.vec(p + "norm1.bias")
+    w.g2, w.b2 = pk.vec(p + "norm2.weight"), pk.vec(p + "norm2.bias")
+    w.conv1, w.cb1 = pk.conv3x3(p + "conv1.weight"), pk.vec(p + "conv1.bias")
+    w.conv2, w.cb2 = pk.conv3x3(p + "conv2.weight"), pk.vec(p + "conv2.bias")
+    w.shortcut = None
+    if pk.has(p + "conv_shortcut.weight"):
+        w.shortcut, w.sb = pk.mat_f16(p + "conv_shortcut.weight"), pk.vec(p + "conv_shortcut.bias")
+    return w
+
+
+def pack_transformer(pk, p):
+    C = pk.sd[p + "norm.weight"].shape[0]
+    b = p + "transformer_blocks.0."
+    w = _NS(C=C, ctx_dim=pk.sd[b + "attn2.to_k.weight"].shape[1])
+    w.gn_g, w.gn_b = pk.vec(p + "norm.weight"), pk.vec(p + "norm.bias")
+    w.proj_in, w.proj_in_b = pk.mat_f16(p + "proj_in.weight"), pk.vec(p + "proj_in.bias")
+    w.proj_out, w.proj_out_b = pk.mat_f16(p + "proj_out.weight"), pk.vec(p + "proj_out.bias")
+    w.ln = [(pk.vec(b + f"norm{i}.weight"), pk.vec(b + f"norm{i}.bias")) for i in (1, 2, 3)]
+    w.qkv1 = pk.mat_f16(b + "attn1.to_q.weight", b + "attn1.to_k.weight", b + "attn1.to_v.weight")
+    w.o1, w.o1_b = pk.mat_f16(b + "attn1.to_out.0.weight"), pk.vec(b + "attn1.to_out.0.bias")
+    w.q2 = pk.mat_f16(b + "attn2.to_q.weight")
+    w.kv2 = pk.mat_f16(b + "attn2.to_k.weight", b + "attn2.to_v.weight")
+    w.o2, w.o2_b = pk.mat_f16(b + "attn2.to_out.0.weight"), pk.vec(b + "attn2.to_out.0.bias")
+    w.ff1, w.ff1_b = pk.geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias")
+    w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
+    return w
+
+
+def pack_motion(pk, p, n_attn):
+    p = p + "temporal_transformer."
+    C = pk.sd[p + "norm.weight"].shape[0]
+    b = p + "transformer_blocks.0."
+    w = _NS(C=C)
+    w.gn_g, w.gn_b = pk.vec(p + "norm.weight"), pk.vec(p + "norm.bias")
+    w.proj_in, w.proj_in_b = pk.mat_f16(p + "proj_in.weight"), pk.vec(p + "proj_in.bias")
+    w.proj_out, w.proj_out_b = pk.mat_f16(p + "proj_out.weight"), pk.vec(p + "proj_out.bias")
+    w.attn = []
+    for i in range(n_attn):
+        a = b + f"attention_blocks.{i}."
+        pe = pk.f32(a + "pos_encoder.pe")[0].contiguous() if pk.has(a + "pos_encoder.pe") else None
+        w.attn.append(_NS(
+            ln_g=pk.vec(b + f"norms.{i}.weight"), ln_b=pk.vec(b + f"norms.{i}.bias"), pe=pe,
+            qkv=pk.mat_f16(a + "to_q.weight", a + "to_k.weight", a + "to_v.weight"),
+            o=pk.mat_f16(a + "to_out.0.weight"), o_b=pk.vec(a + "to_out.0.bias")))
+    w.ff_ln = (pk.vec(b + "ff_norm.weight"), pk.vec(b + "ff_norm.bias"))
+    w.ff1, w.ff1_b = pk.geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias")
+    w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
+    return w
+
+
+# ------------------------------------------------------------------------------------------------
+# block emitters
+
+class Geo:
+    """b samples x f frames of H x W latent pixels."""
+
+    def __init__(self, b, f, H, W):
+        self.b, self.f, self.H, self.W = b, f, H, W
+        self.n_img = b * f
+        self.hw = H * W
+        self.M = self.n_img * self.hw
+
+
+def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0):
+    """ResnetBlock3D.forward (src/models/resnet.py:182-212).  temb = (tensor [b][ldt] fp32, col offset, ldt)
+    = this block's slice of the batched time_emb_proj(silu(emb)) table.  x may be a concat view."""
+    g = geo
+    a1 = plan.rows("norm", g.M, x.C)
+    emit_groupnorm(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, True, a1, groups)
+    h1 = plan.rows("res_h1", g.M, w.cout)
+    emit_conv3x3(plan, a1, g.n_img, g.H, g.W, w.conv1, w.cin, w.cout, h1, bias=w.cb1,
+                 rowvec=(temb[0], temb[1], temb[2], g.f * g.hw))
+    a2 = plan.rows("norm", g.M, w.cout)
+    emit_groupnorm(plan, h1, g.b, g.f * g.hw, w.g2, w.b2, eps, True, a2, groups)
+    res = x
+    if w.shortcut is not None:
+        res = plan.rows("res_sc", g.M, w.cout)
+        emit_gemm(plan, x, w.shortcut, w.cout, w.cin, res, bias=w.sb)
+    emit_conv3x3(plan, a2, g.n_img, g.H, g.W, w.conv2, w.cout, w.cout, out, bias=w.cb2, residual=res, scale=out_scale)
+
+
+def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C):
+    """x += FeedForward_geglu(LayerNorm(x))  (attention.py:514 / motion_module.py:243), in place on tok."""
+    emit_layernorm(plan, tok, ln_g, ln_b, a)
+    gg = plan.rows("geglu", M, 4 * C)
+    emit_gemm(plan, a, ff1, 8 * C, C, gg, bias=ff1_b, geglu=True)
+    emit_gemm(plan, gg, ff2, C, 4 * C, tok, bias=ff2_b, residual=tok)
+
+
+def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32):
+    """Transformer3DModel.forward + BasicTransformerBlock.forward (src/models/attention.py:318-365,479-526).
+    ctx_kv: Rows [n_img*L][2C] = [K | V] projections of the context for this site (computed per context)."""
+    g, C = geo, w.C
+    d_head = C // heads
+    a = plan.rows("norm", g.M, C)
+    emit_groupnorm(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, False, a, groups)
+    tok = plan.rows("tok", g.M, C)
+    emit_gemm(plan, a, w.proj_in, C, C, tok, bias=w.proj_in_b)
+    # self-attention over the hw patches of each frame
+    emit_layernorm(plan, tok, w.ln[0][0], w.ln[0][1], a)
+    qkv = plan.rows("qkv", g.M, 3 * C)
+    emit_gemm(plan, a, w.qkv1, 3 * C, C, qkv)
+    ao = plan.rows("attn_out", g.M, C)
+    emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), g.n_img, heads, g.hw, g.hw, d_head, ao)
+    emit_gemm(plan, ao, w.o1, C, C, tok, bias=w.o1_b, residual=tok)
+    # cross-attention over the L context rows of that frame
+    emit_layernorm(plan, tok, w.ln[1][0], w.ln[1][1], a)
+    qc = plan.rows("qkv", g.M, C)
+    emit_gemm(plan, a, w.q2, C, C, qc)
+    emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), g.n_img, heads, g.hw, L, d_head, ao)
+    emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok)
+    emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, g.M, C)
+    emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
+
+
+def emit_ctx_kv(plan, w, ctx16, ctx_kv):
+    """[K | V] = ctx [to_k; to_v]^T  (CrossAttention.forward attention.py:139-141) — context only."""
+    emit_gemm(plan, ctx16, w.kv2, 2 * w.C, w.ctx_dim, ctx_kv)
+
+
+def emit_motion(plan, w, x, geo, heads, out, groups=32):
+    """VanillaTemporalModule -> TemporalTransformer3DModel.forward -> TemporalTransformerBlock.forward
+    (src/models/motion_module.py:87-93,147-182,234-246)."""
+    g, C = geo, w.C
+    d_head = C // heads
+    a = plan.rows("norm", g.M, C)
+    emit_groupnorm(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, False, a, groups)
+    tok = plan.rows("tok", g.M, C)
+    emit_gemm(plan, a, w.proj_in, C, C, tok, bias=w.proj_in_b)
+    for at in w.attn:
+        emit_layernorm(plan, tok, at.ln_g, at.ln_b, a, pe=at.pe, rows_per_frame=g.hw, frames=g.f)
+        qkv = plan.rows("qkv", g.M, 3 * C)
+        emit_gemm(plan, a, at.qkv, 3 * C, C, qkv)
+        ao = plan.rows("attn_out", g.M, C)
+        emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)
+        emit_gemm(plan, ao, at.o, C, C, tok, bias=at.o_b, residual=tok)
+    emit_ff(plan, tok, w.ff_ln[0], w.ff_ln[1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, g.M, C)
+    emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
+
+
+# ------------------------------------------------------------------------------------------------
+# the whole UNet
+
+CIN_PAD = 64   # conv_in reads its 9 channels from a 64-wide zero-padded row (one BK step per tap)
+COUT_PAD = 8   # conv_out writes 4 channels + 4 zero columns (16-byte rows)
+
+
+class UNetProgram:
+    """Static launch plan of one UNet3DConditionModel.forward for fixed (b, f, H, W, L)."""
+
+    def __init__(self, cfg, sd, b, frames, H, W, L, device):
+        if H % 8 or W % 8:
+            raise hip.RcdmError(f"latent size {H}x{W} must be a multiple of 8 on the HIP path")
+        self.cfg, self.b, self.f, self.H, self.W, self.L = cfg, b, frames, H, W, L
+        self.device = torch.device(device)
+        self.plan = plan = Plan(device)
+        self.ctx_plan_ops = []
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.graph = None
+        self.calls = 0
+        self.ctx_key = None
+        boc = list(cfg["block_out_channels"])
+        lpb = cfg["layers_per_block"]
+        heads, groups, eps = cfg["attention_head_dim"], cfg["norm_num_groups"], cfg["norm_eps"]
+        mheads, n_attn = cfg["motion_num_attention_heads"], cfg["motion_attention_blocks"]
+        nlev = len(boc)
+        geos = [Geo(b, frames, H >> l, W >> l) for l in range(nlev)]
+        self.geos = geos
+        pk = Packer(sd, device)
+        ted = boc[0] * 4
+
+        def has_motion(res):
+            return cfg["use_motion_module"] and res in cfg["motion_module_resolutions"]
+
+        # ---- time embedding chain (unet.py:381-389) + all time_emb_proj batched (resnet.py:191) ----
+        self.t_dev = torch.zeros(b, dtype=torch.float32, device=self.device)
+        temb0 = torch.zeros(b, boc[0], dtype=torch.float32, device=self.device)
+        temb1 = torch.zeros(b, ted, dtype=torch.float32, device=self.device)
+        emb = torch.zeros(b, ted, dtype=torch.float32, device=self.device)
+        te_w1, te_b1 = pk.mat_f16("time_embedding.linear_1.weight"), pk.vec("time_embedding.linear_1.bias")
+        te_w2, te_b2 = pk.mat_f16("time_embedding.linear_2.weight"), pk.vec("time_embedding.linear_2.bias")
+        resnet_prefixes = []
+        for i, kind in enumerate(cfg["down_block_types"]):
+            resnet_prefixes += [f"down_blocks.{i}.resnets.{j}." for j in range(lpb)]
+        resnet_prefixes += ["mid_block.resnets.0.", "mid_block.resnets.1."]
+        for i, kind in enumerate(cfg["up_block_types"]):
+            resnet_prefixes += [f"up_blocks.{i}.resnets.{j}." for j in range(lpb + 1)]
+        tp_off, off = {}, 0
+        for p in resnet_prefixes:
+            tp_off[p] = off
+            off += sd[p + "time_emb_proj.weight"].shape[0]
+        tp_total = off
+        tp_w = pk.mat_f16(*[p + "time_emb_proj.weight" for p in resnet_prefixes])
+        tp_b = torch.cat([pk.vec(p + "time_emb_proj.bias") for p in resnet_prefixes]).contiguous()
+        tproj = torch.zeros(b, tp_total, dtype=torch.float32, device=self.device)
+        plan.keep += [self.t_dev, temb0, temb1, emb, tproj, te_w1, te_b1, te_w2, te_b2, tp_w, tp_b]
+
+        def small_linear_rows(x, K, Wm, bias, N, si, so, outt):
+            for r0 in range(0, b, 8):
+                r = min(8, b - r0)
+                plan.add(lambda x=x, r0=r0, r=r: hip.small_linear(
+                    x.data_ptr() + 4 * r0 * K, r, K, Wm.data_ptr(), bias.data_ptr(), N, si, so,
+                    outt.data_ptr() + 4 * r0 * N))
+                plan.n_launch += 1
+
+        plan.add(lambda: hip.timestep_embed(self.t_dev.data_ptr(), b, boc[0], temb0.data_ptr()))
+        plan.n_launch += 1
+        small_linear_rows(temb0, boc[0], te_w1, te_b1, ted, 0, 1, temb1)
+        small_linear_rows(temb1, ted, te_w2, te_b2, ted, 0, 0, emb)
+        small_linear_rows(emb, ted, tp_w, tp_b, tp_total, 1, 0, tproj)
+
+        def temb_of(p):
+            return (tproj, tp_off[p], tp_total)
+
+        # ---- skip/concat layout: simulate the up path to learn each concat buffer's width ----------
+        skip_specs = [(boc[0], 0)]
+        for i in range(nlev):
+            skip_specs += [(boc[i], i)] * lpb
+            if i != nlev - 1:
+                skip_specs.append((boc[i], i + 1))
+        n_skip = len(skip_specs)
+        rev = list(reversed(boc))
+        h_ch, k = boc[-1], n_skip
+        cat_hch = {}
+        for i in range(nlev):
+            for j in range(lpb + 1):
+                k -= 1
+                cat_hch[k] = h_ch
+                h_ch = rev[i]
+        assert k == 0
+        cats = {}
+        for k, (c, lvl) in enumerate(skip_specs):
+            width = cat_hch[k] + c
+            cats[k] = plan.rows(f"cat{k}", geos[lvl].M, width, unique=True)
+
+        def skip_view(k):
+            return cats[k].cols(cat_hch[k], skip_specs[k][0])
+
+        def h_view(k):
+            return cats[k].cols(0, cat_hch[k])
+
+        # ---- input / conv_in ------------------------------------------------------------------------
+        g0 = geos[0]
+        self.x_in = plan.rows("x_in", g0.M, CIN_PAD, unique=True)
+        conv_in_w = pk.conv3x3("conv_in.weight", cin_pad=CIN_PAD)
+        self.in_channels = sd["conv_in.weight"].shape[1]
+        emit_conv3x3(plan, self.x_in, g0.n_img, g0.H, g0.W, conv_in_w, CIN_PAD, boc[0], skip_view(0),
+                     bias=pk.vec("conv_in.bias"))
+
+        # ---- cross-attention context: per-site [K|V] buffers, filled by the context plan -------------
+        ctx_dim = cfg["cross_attention_dim"]
+        self.ctx16 = plan.rows("ctx16", g0.n_img * L, ctx_dim, unique=True)
+        ctx_plan = Plan(device)
+        ctx_plan.bufs = plan.bufs  # share buffers (split-K workspace) and materialisation
+        self._ctx_plan = ctx_plan
+        site = [0]
+
+        def transformer(p, x, geo, out):
+            w = pack_transformer(pk, p)
+            kv = plan.rows(f"ctx_kv{site[0]}", geo.n_img * L, 2 * w.C, unique=True)
+            site[0] += 1
+            emit_ctx_kv(ctx_plan, w, self.ctx16, kv)
+            emit_transformer(plan, w, x, geo, kv, L, heads, out, groups)
+
+        def motion(p, x, geo, out):
+            emit_motion(plan, pack_motion(pk, p, n_attn), x, geo, mheads, out, groups)
+
+        def layer(pb, j, kind_attn, res, x, geo, final_out):
+            """resnet -> [transformer] -> [motion]; the LAST op writes final_out, the others ping-pong."""
+            stages = ["r"] + (["t"] if kind_attn else []) + (["m"] if has_motion(res) else [])
+            cur = x
+            cout = sd[pb + f"resnets.{j}.conv1.weight"].shape[0]
+            for si, st in enumerate(stages):
+                dst = final_out if si == len(stages) - 1 else plan.rows(f"blk{si % 2}", geo.M, cout)
+                if st == "r":
+                    pr = pb + f"resnets.{j}."
+                    emit_resnet(plan, pack_resnet(pk, pr), cur, geo, temb_of(pr), dst, eps, groups)
+                elif st == "t":
+                    transformer(pb + f"attentions.{j}.", cur, geo, dst)
+                else:
+                    motion(pb + f"motion_modules.{j}.", cur, geo, dst)
+                cur = dst
+            return cur
+
+        # ---- down path ------------------------------------------------------------------------------
+        cur, k = skip_view(0), 1
+        for i, kind in enumerate(cfg["down_block_types"]):
+            pb = f"down_blocks.{i}."
+            for j in range(lpb):
+                cur = layer(pb, j, kind == "CrossAttnDownBlock3D", 2 ** i, cur, geos[i], skip_view(k))
+                k += 1
+            if i != nlev - 1:
+                dsw = pk.conv3x3(pb + "downsamplers.0.conv.weight")
+                emit_conv3x3(plan, cur, geos[i].n_img, geos[i].H, geos[i].W, dsw, boc[i], boc[i], skip_view(k),
+                             stride=2, bias=pk.vec(pb + "downsamplers.0.conv.bias"))
+                cur = skip_view(k)
+                k += 1
+        assert k == n_skip
+
+        # ---- mid block (unet_blocks.py:272-280) ------------------------------------------------------
+        gm = geos[-1]
+        m0 = plan.rows("blk0", gm.M, boc[-1])
+        emit_resnet(plan, pack_resnet(pk, "mid_block.resnets.0."), cur, gm, temb_of("mid_block.resnets.0."), m0,
+                    eps, groups, 1.0 / cfg.get("mid_block_scale_factor", 1))
+        m1 = plan.rows("blk1", gm.M, boc[-1])
+        transformer("mid_block.attentions.0.", m0, gm, m1)
+        cur = m1
+        if cfg["use_motion_module"] and cfg["motion_module_mid_block"]:
+            m2 = plan.rows("blk0", gm.M, boc[-1])
+            motion("mid_block.motion_modules.0.", m1, gm, m2)
+            cur = m2
+        k = n_skip - 1
+        emit_resnet(plan, pack_resnet(pk, "mid_block.resnets.1."), cur, gm, temb_of("mid_block.resnets.1."),
+                    h_view(k), eps, groups, 1.0 / cfg.get("mid_block_scale_factor", 1))
+
+        # ---- up path ---------------------------------------------------------------------------------
+        final = plan.rows("final", g0.M, boc[0], unique=True)
+        for i, kind in enumerate(cfg["up_block_types"]):
+            pb = f"up_blocks.{i}."
+            lvl = nlev - 1 - i
+            geo = geos[lvl]
+            last_block = i == nlev - 1
+            for j in range(lpb + 1):
+                x = cats[k]  # [h | skip] full-width view
+                last_layer = j == lpb
+                if not last_layer:
+                    dst = h_view(k - 1)
+                elif last_block:
+                    dst = final
+                else:
+                    dst = plan.rows("up_tmp", geo.M, rev[i])
+                cur = layer(pb, j, kind == "CrossAttnUpBlock3D", 2 ** (nlev - 1 - i), x, geo, dst)
+                k -= 1
+            if not last_block:
+                usw = pk.conv3x3(pb + "upsamplers.0.conv.weight")
+                emit_conv3x3(plan, cur, geo.n_img, geo.H, geo.W, usw, rev[i], rev[i], h_view(k), up=1,
+                             bias=pk.vec(pb + "upsamplers.0.conv.bias"))
+        assert k == -1
+
+        # ---- output head (unet.py:455-457) -------------------------------------------------------------
+        a = plan.rows("norm", g0.M, boc[0])
+        emit_groupnorm(plan, final, b, frames * g0.hw, pk.vec("conv_norm_out.weight"), pk.vec("conv_norm_out.bias"),
+                       eps, True, a, groups)
+        self.out_channels = sd["conv_out.weight"].shape[0]
+        co_w = pk.conv3x3("conv_out.weight", cout_pad=COUT_PAD)
+        co_b = torch.cat([pk.vec("conv_out.bias"),
+                          torch.zeros(COUT_PAD - self.out_channels, device=self.device)]).contiguous()
+        self.eps_out = plan.rows("eps_out", g0.M, COUT_PAD, unique=True)
+        emit_conv3x3(plan, a, g0.n_img, g0.H, g0.W, co_w, boc[0], COUT_PAD, self.eps_out, bias=co_b)
+
+        pk.done()
+        plan.materialize()
+        self.n_sites = site[0]
+
+    # ---- context ---------------------------------------------------------------------------------
+    def set_context(self, ctx):
+        """ctx (b*f, L, D) any float dtype/device.  Recomputes the 16 [K|V] projections only if the
+        context changed (the reference recomputes them every step, attention.py:139-141)."""
+        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape), ctx.dtype, ctx.device)
+        if key == self.ctx_key:
+            return
+        n_img = self.b * self.f
+        if tuple(ctx.shape) != (n_img, self.L, self.cfg["cross_attention_dim"]):
+            raise hip.RcdmError(f"encoder_hidden_states shape {tuple(ctx.shape)} != "
+                                f"{(n_img, self.L, self.cfg['cross_attention_dim'])}")
+        src = ctx.detach().to(self.device, torch.float32).contiguous()
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            hip.pack_f16(src.data_ptr(), self.ctx16.ptr, src.numel())
+            self._ctx_plan.run()
+        cur.wait_stream(self.stream)
+        src.record_stream(self.stream)
+        self.ctx_key = key
+
+    # ---- execution -------------------------------------------------------------------------------
+    def run_body(self):
+        """Enqueue the UNet body on torch's current stream (inputs: x_in rows, t_dev; output: eps_out)."""
+        self.plan.run()
+
+    def capture(self, pre=None, post=None):
+        """Capture [pre ops] + body + [post ops] into a hipGraph on the program's stream."""
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.stream(self.stream):
+            g = hip.Graph()
+            g.begin()
+            try:
+                for op in (pre or []):
+                    op()
+                self.plan.run()
+                for op in (post or []):
+                    op()
+            finally:
+                g.end()
+        torch.cuda.synchronize(self.device)
+        return g
+
+    def forward(self, sample, timestep, ctx, use_graph=True):
+        """UNet3DConditionModel.forward semantics: sample (b,Cin,f,H,W) -> (b,Cout,f,H,W) fp32."""
+        b, f, H, W = self.b, self.f, self.H, self.W
+        self.set_context(ctx)
+        x = sample.detach().to(self.device, torch.float32).contiguous()
+        t = torch.as_tensor(timestep, dtype=torch.float32, device=self.device).reshape(-1)
+        out = torch.empty(b, self.out_channels, f, H, W, dtype=torch.float32, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.t_dev.copy_(t.expand(b))
+            hip.ncfhw_to_rows(x.data_ptr(), b, self.in_channels, f, H, W, self.x_in.ptr, self.x_in.ld, CIN_PAD)
+            if use_graph and self.calls >= 1:
+                if self.graph is None:
+                    # capture() synchronises; the first (eager) call has already warmed every kernel up
+                    self.graph = self.capture()
+                self.graph.launch()
+            else:
+                self.plan.run()
+            self.calls += 1
+            hip.rows_to_ncfhw(self.eps_out.ptr, self.eps_out.ld, b, self.out_channels, f, H, W, out.data_ptr())
+        cur.wait_stream(self.stream)
+        x.record_stream(self.stream)
+        out.record_stream(self.stream)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# block-level runners (module.forward of the mirrored classes): pack, plan, run eagerly.
+
+def rows_from_ncfhw(x):
+    b, c, f, h, w = x.shape
+    x = x.detach().to(torch.float32).contiguous()
+    cp = (c + 7) // 8 * 8
+    rows = torch.empty(b * f * h * w, cp, dtype=torch.float16, device=x.device)
+    hip.ncfhw_to_rows(x.data_ptr(), b, c, f, h, w, rows.data_ptr(), cp, cp)
+    return rows
+
+
+def ncfhw_from_rows(rows, ld, b, c, f, h, w):
+    out = torch.empty(b, c, f, h, w, dtype=torch.float32, device=rows.device)
+    hip.rows_to_ncfhw(rows.data_ptr(), ld, b, c, f, h, w, out.data_ptr())
+    return out
+
+
+class _Holder:
+    def __init__(self, t):
+        self.t = t
+        self.nbytes = t.numel() * t.element_size()
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+def _as_rows(t, M, C, ld):
+    return Rows(_Holder(t), 0, M, C, ld)
+
+
+def run_block(kind, sd, x, device=None, **kw):
+    """Run ONE reference block on the HIP path: kind in {"resnet","transformer","motion","down","up","conv"}.
+    x (b,C,f,H,W); returns (b,C',f,H',W') fp32.  Used by the mirrored nn.Module classes' forward()."""
+    if not x.is_cuda:
+        raise hip.RcdmError("rcdms_amd runs on MI355X only: input tensor is not on a CUDA/HIP device (no CPU fallback)")
+    device = x.device
+    b, c, f, H, W = x.shape
+    geo = Geo(b, f, H, W)
+    plan = Plan(device)
+    pk = Packer(sd, device)
+    xr_t = rows_from_ncfhw(x)
+    xr = _as_rows(xr_t, geo.M, c, xr_t.shape[1])
+    groups = kw.get("groups", 32)
+    if kind == "resnet":
+        w = pack_resnet(pk, "")
+        temb = kw["temb"].detach().to(device, torch.float32)
+        tp_w = pk.mat_f16("time_emb_proj.weight")
+        tp_b = pk.vec("time_emb_proj.bias")
+        tproj = torch.empty(b, w.cout, dtype=torch.float32, device=device)
+        for r0 in range(0, b, 8):
+            r = min(8, b - r0)
+            hip.small_linear(temb.data_ptr() + 4 * r0 * temb.shape[1], r, temb.shape[1], tp_w.data_ptr(),
+                             tp_b.data_ptr(), w.cout, 1, 0, tproj.data_ptr() + 4 * r0 * w.cout)
+        out = plan.rows("out", geo.M, w.cout, unique=True)
+        emit_resnet(plan, w, xr, geo, (tproj, 0, w.cout), out, kw.get("eps", 1e-5), groups,
+                    1.0 / kw.get("output_scale_factor", 1.0))
+        oc, oh, ow = w.cout, H, W
+    elif kind == "transformer":
+        w = pack_transformer(pk, "")
+        ctx = kw["ctx"].detach().to(device, torch.float32).contiguous()
+        L = ctx.shape[1]
+        ctx16 = plan.rows("ctx16", geo.n_img * L, w.ctx_dim, unique=True)
+        kv = plan.rows("ctx_kv", geo.n_img * L, 2 * w.C, unique=True)
+        plan.add(lambda: hip.pack_f16(ctx.data_ptr(), ctx16.ptr, ctx.numel()))
+        emit_ctx_kv(plan, w, ctx16, kv)
+        out = plan.rows("out", geo.M, c, unique=True)
+        emit_transformer(plan, w, xr, geo, kv, L, kw["heads"], out, groups)
+        oc, oh, ow = c, H, W
+    elif kind == "motion":
+        w = pack_motion(pk, "", kw["n_attn"])
+        out = plan.rows("out", geo.M, c, unique=True)
+        emit_motion(plan, w, xr, geo, kw["heads"], out, groups)
+        oc, oh, ow = c, H, W
+    elif kind in ("down", "up", "conv"):
+        cw = sd["weight"] if kind == "conv" else sd["conv.weight"]
+        cbk = "bias" if kind == "conv" else "conv.bias"
+        oc = cw.shape[0]
+        ocp = (oc + 7) // 8 * 8
+        ksz = cw.shape[-1]
+        stride = kw.get("stride", 2 if kind == "down" else 1)
+        up = 1 if kind == "up" else 0
+        cp = xr_t.shape[1]
+        bias = None
+        if cbk in sd and sd[cbk] is not None:
+            bias = torch.cat([pk.vec(cbk), torch.zeros(ocp - oc, device=device)]).contiguous()
+        if ksz == 3:
+            wk = "weight" if kind == "conv" else "conv.weight"
+            wt = pk.conv3x3(wk, cin_pad=cp, cout_pad=ocp)
+            oh, ow = ((H << up) - 1) // stride + 1, ((W << up) - 1) // stride + 1
+            out = plan.rows("out", geo.n_img * oh * ow, ocp, unique=True)
+            emit_conv3x3(plan, Rows(xr.buf, 0, geo.M, cp, cp), geo.n_img, H, W, wt, cp, ocp, out, stride=stride, up=up,
+                         bias=bias)
+        elif ksz == 1:
+            w2 = torch.zeros(ocp, cp, device=device)
+            w2[:oc, :c] = pk.f32("weight").reshape(oc, c)
+            wt = torch.empty(ocp, cp, dtype=torch.float16, device=device)
+            hip.pack_f16(w2.data_ptr(), wt.data_ptr(), w2.numel())
+            oh, ow = H, W
+            out = plan.rows("out", geo.M, ocp, unique=True)
+            emit_gemm(plan, Rows(xr.buf, 0, geo.M, cp, cp), wt, ocp, cp, out, bias=bias)
+            plan.keep.append(w2)
+        else:
+            raise hip.RcdmError(f"conv kernel size {ksz} not supported on the HIP path")
+    else:
+        raise ValueError(kind)
+    pk.done()
+    plan.materialize()
+    plan.run()
+    res = ncfhw_from_rows(out.buf.t.view(torch.float16), out.ld, b, oc, f, oh, ow)
+    torch.cuda.synchronize(device)
+    return res

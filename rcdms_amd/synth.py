@@ -1,0 +1,78 @@
+"""Procedural (name-seeded) weights and the synthetic stage-2 story of SURVEY.md §8(d).
+
+There are no checkpoints or datasets in this environment, so every parity fixture and the bench use
+weights generated from the parameter NAME: the same tensor is regenerated bit-identically on the build
+container (where the reference model is imported to mint golden outputs) and on the GPU box, without
+shipping 5 GB of weights.  numpy's Philox bit generator is platform-stable.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+
+def _rng(name, seed):
+    return np.random.Generator(np.random.Philox(key=[zlib.crc32(name.encode()) & 0xFFFFFFFF, seed & 0xFFFFFFFF]))
+
+
+def sinusoid_table(d_model, max_len):
+    """The fixed (non-learned) `pos_encoder.pe` buffer of the reference's PositionalEncoding
+    (src/models/motion_module.py:258-263) — part of the 1286-key state dict."""
+    pos = torch.arange(max_len, dtype=torch.float32)[:, None]
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(1, max_len, d_model)
+    pe[0, :, 0::2] = torch.sin(pos * div)
+    pe[0, :, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+def procedural_tensor(name, shape, seed=0):
+    """Value of parameter `name`:
+      *.pe                         -> the sinusoid table (a buffer, not random)
+      norm weights (1-D "*.weight" of a norm) -> 1 + 0.1 N(0,1); 1-D biases -> 0.05 N(0,1)
+      matrices / conv kernels      -> N(0, 1/fan_in)  (unit gain, keeps activations O(1))."""
+    shape = tuple(int(s) for s in shape)
+    if name.endswith("pos_encoder.pe"):
+        return sinusoid_table(shape[2], shape[1])
+    g = _rng(name, seed)
+    x = g.standard_normal(size=shape, dtype=np.float32)
+    if len(shape) == 1:
+        if name.endswith(".weight") and _is_norm_param(name):
+            x = 1.0 + 0.1 * x
+        else:
+            x = 0.05 * x
+    else:
+        fan_in = int(np.prod(shape[1:]))
+        x = x * (1.0 / math.sqrt(fan_in))
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def _is_norm_param(name):
+    parts = name.split(".")
+    owner = parts[-2]
+    if owner.isdigit():  # "...norms.0.weight"
+        owner = parts[-3]
+    return "norm" in owner
+
+
+def procedural_state_dict(shapes, seed=0):
+    """shapes: mapping parameter name -> shape (e.g. from `state_shapes(cfg)` or a module's state_dict)."""
+    return {k: procedural_tensor(k, tuple(v), seed) for k, v in shapes.items()}
+
+
+def synthetic_story(stories=1, frames=5, latent_hw=(64, 64), ctx_len=85, ctx_dim=768, cfg=True, seed=42):
+    """CPU-seeded inputs of the denoising loop for `stories` stories.
+    Returns dict(latents (S,4,f,h,w), mask (R*S,1,f,h,w), masked_latents (R*S,4,f,h,w), ctx (R*S*f, L, D)),
+    R = 2 with CFG.  mask = [1,0,0,0,0] per story (first frame seen), masked latents of unseen frames are a
+    constant (the stand-in for the VAE latent of a black frame, RCDMs_pipeline.py:427-432)."""
+    g = torch.Generator().manual_seed(seed)
+    h, w = latent_hw
+    reps = 2 if cfg else 1
+    lat = torch.randn(stories, 4, frames, h, w, generator=g)
+    ml = 0.18215 * torch.randn(stories, 4, frames, h, w, generator=g)
+    ml[:, :, 1:] = 0.18215 * torch.tensor([0.9, -0.6, 0.3, -1.2]).view(1, 4, 1, 1, 1)
+    mask = torch.zeros(stories, 1, frames, h, w)
+    mask[:, :, 0] = 1.0
+    ctx = torch.randn(reps * stories * frames, ctx_len, ctx_dim, generator=g)
+    return dict(latents=lat, mask=torch.cat([mask] * reps), masked_latents=torch.cat([ml] * reps), ctx=ctx)

@@ -99,7 +99,8 @@ def test_gemm_transpose_detecting(hiplib):
     W = h16(W)
     out = torch.empty(M, N, dtype=torch.float16, device=DEV)
     d = hip.GemmDesc(M, N, K, K, N, N, 0, 1, 0, 1.0, 1)
-    hip.gemm(d, A.half().to(DEV).data_ptr(), W.half().to(DEV).data_ptr(), 0, 0, 0, out.data_ptr(), 0, 0)
+    Ad, Wd = A.half().to(DEV), W.half().to(DEV)
+    hip.gemm(d, Ad.data_ptr(), Wd.data_ptr(), 0, 0, 0, out.data_ptr(), 0, 0)
     torch.cuda.synchronize()
     close(out, W.t(), rel=1e-3, abs_frac=1e-3)
 
@@ -117,12 +118,12 @@ def test_gemm_geglu(hiplib, split):
     ref = hidden * F.gelu(gate)
     wp = torch.empty(8 * C, C, dtype=torch.float16, device=DEV)
     bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
-    hip.pack_geglu_rows(sd["ff.net.0.proj.weight"].to(DEV).data_ptr(), sd["ff.net.0.proj.bias"].to(DEV).data_ptr(),
-                        8 * C, C, wp.data_ptr(), bp.data_ptr())
+    w32, b32, xd = sd["ff.net.0.proj.weight"].to(DEV), sd["ff.net.0.proj.bias"].to(DEV), x.half().to(DEV)
+    hip.pack_geglu_rows(w32.data_ptr(), b32.data_ptr(), 8 * C, C, wp.data_ptr(), bp.data_ptr())
     out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
     d = hip.GemmDesc(M, 8 * C, C, C, 4 * C, 0, hip.EPI_BIAS | hip.EPI_GEGLU, 1, 0, 1.0, split)
     w = ws(hip.gemm_workspace_bytes(d))
-    hip.gemm(d, x.half().to(DEV).data_ptr(), wp.data_ptr(), bp.data_ptr(), 0, 0, out.data_ptr(), w.data_ptr(), w.numel())
+    hip.gemm(d, xd.data_ptr(), wp.data_ptr(), bp.data_ptr(), 0, 0, out.data_ptr(), w.data_ptr(), w.numel())
     torch.cuda.synchronize()
     close(out, ref)
 
@@ -150,7 +151,8 @@ def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split):
     xd = rows_from_5d(x, lda)
     rd = rows_from_5d(res)
     wp = torch.empty(cout, 9 * cin, dtype=torch.float16, device=DEV)
-    hip.pack_conv3x3(w.to(DEV).data_ptr(), cout, cin, cin, wp.data_ptr())
+    w32 = w.to(DEV)
+    hip.pack_conv3x3(w32.data_ptr(), cout, cin, cin, wp.data_ptr())
     out = torch.empty(b * f * Ho * Wo, cout, dtype=torch.float16, device=DEV)
     d = hip.ConvDesc(b * f, H, W, cin, cout, stride, up, lda, cout, cout,
                      hip.EPI_BIAS | hip.EPI_ROWVEC | hip.EPI_RESIDUAL, f * Ho * Wo, cout, 1.0, split)
@@ -278,7 +280,8 @@ def test_temporal_attn(hiplib, b, frames, pixels, heads, d):
     ref = o.reshape(b, pixels, frames, C).permute(0, 2, 1, 3).reshape(b * frames * pixels, C)
     out = torch.empty(b * frames * pixels, C, dtype=torch.float16, device=DEV)
     desc = hip.TemporalAttnDesc(b, frames, pixels, heads, d, 3 * C, C, d ** -0.5)
-    hip.temporal_attn(desc, qkv.half().to(DEV).data_ptr(), out.data_ptr())
+    qkv_d = qkv.half().to(DEV)
+    hip.temporal_attn(desc, qkv_d.data_ptr(), out.data_ptr())
     torch.cuda.synchronize()
     close(out, ref)
 
@@ -289,18 +292,21 @@ def test_timestep_embed_and_small_linear(hiplib):
     t = torch.tensor([981.0, 981.0, 1.0])
     ref = O.timestep_embedding(t, 320)
     out = torch.empty(3, 320, device=DEV)
-    hip.timestep_embed(t.to(DEV).data_ptr(), 3, 320, out.data_ptr())
+    t_d = t.to(DEV)
+    hip.timestep_embed(t_d.data_ptr(), 3, 320, out.data_ptr())
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() < 2e-4
     W1 = h16(torch.randn(1280, 320, generator=g) * 0.05)
     b1 = torch.randn(1280, generator=g)
     ref2 = F.silu(F.linear(ref, W1, b1))
     o2 = torch.empty(3, 1280, device=DEV)
-    hip.small_linear(out.data_ptr(), 3, 320, W1.half().to(DEV).data_ptr(), b1.to(DEV).data_ptr(), 1280, 0, 1, o2.data_ptr())
+    W1d, b1d = W1.half().to(DEV), b1.to(DEV)
+    hip.small_linear(out.data_ptr(), 3, 320, W1d.data_ptr(), b1d.data_ptr(), 1280, 0, 1, o2.data_ptr())
     W2 = h16(torch.randn(200, 1280, generator=g) * 0.03)
     ref3 = F.linear(F.silu(ref2), W2)
     o3 = torch.empty(3, 200, device=DEV)
-    hip.small_linear(o2.data_ptr(), 3, 1280, W2.half().to(DEV).data_ptr(), 0, 200, 1, 0, o3.data_ptr())
+    W2d = W2.half().to(DEV)
+    hip.small_linear(o2.data_ptr(), 3, 1280, W2d.data_ptr(), 0, 200, 1, 0, o3.data_ptr())
     torch.cuda.synchronize()
     close(o2, ref2, rel=1e-3, abs_frac=1e-3)
     close(o3, ref3, rel=1e-3, abs_frac=1e-3)
@@ -315,15 +321,16 @@ def test_layout_and_ddim(hiplib):
     masked = torch.randn(2 * S, 4, f, H, W, generator=g)
     ref_in = torch.cat([torch.cat([lat] * 2), mask, masked], dim=1)       # RCDMs_pipeline.py:482-486
     rows = torch.full((2 * S * f * H * W, 64), float("nan"), dtype=torch.float16, device=DEV)
-    hip.assemble_input(lat.to(DEV).data_ptr(), mask.to(DEV).data_ptr(), masked.to(DEV).data_ptr(), S, 2, f, H, W,
-                       rows.data_ptr(), 64, 64)
+    lat0, mask_d, masked_d = lat.to(DEV), mask.to(DEV), masked.to(DEV)
+    hip.assemble_input(lat0.data_ptr(), mask_d.data_ptr(), masked_d.data_ptr(), S, 2, f, H, W, rows.data_ptr(), 64, 64)
     torch.cuda.synchronize()
     close(rows_to_5d(rows, 2 * S, 9, f, H, W), ref_in, rel=1e-3, abs_frac=1e-3)
     assert (rows[:, 9:] == 0).all()
     # generic converters round-trip
     x = torch.randn(3, 9, f, H, W, generator=g)
     r2 = torch.empty(3 * f * H * W, 16, dtype=torch.float16, device=DEV)
-    hip.ncfhw_to_rows(x.to(DEV).data_ptr(), 3, 9, f, H, W, r2.data_ptr(), 16, 16)
+    x_d = x.to(DEV)
+    hip.ncfhw_to_rows(x_d.data_ptr(), 3, 9, f, H, W, r2.data_ptr(), 16, 16)
     back = torch.empty(3, 9, f, H, W, device=DEV)
     hip.rows_to_ncfhw(r2.data_ptr(), 16, 3, 9, f, H, W, back.data_ptr())
     torch.cuda.synchronize()

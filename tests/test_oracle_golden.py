@@ -1,0 +1,157 @@
+"""CPU: the oracle restatement (oracle/unet_oracle.py) against the golden vectors minted from the
+REFERENCE's own classes (oracle/make_golden.py), and the mirrored `src.models` classes' state-dict layout
+against the reference's (key/shape digest stored in every fixture).  fp32 on both sides: tolerance 2e-4
+relative to the output scale (different op ordering only)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+from rcdms_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+MOTION_KW = dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
+                 temporal_position_encoding=True, temporal_position_encoding_max_len=5, temporal_attention_dim_div=1,
+                 zero_initialize=True)
+UNET_KW = dict(use_motion_module=True, motion_module_resolutions=[1, 2, 4, 8], unet_use_cross_frame_attention=False,
+               unet_use_temporal_attention=False, motion_module_type="Vanilla", motion_module_kwargs=MOTION_KW)
+
+
+def gold(name):
+    path = os.path.join(GOLD, name + ".npz")
+    assert os.path.exists(path), f"missing golden fixture {path} (python -m oracle.make_golden)"
+    z = np.load(path)
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim else z[k].item()) for k in z.files}
+
+
+def digest(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(f"{k}:{tuple(sd[k].shape)};".encode())
+    return h.hexdigest()
+
+
+def shapes_of(module):
+    return {k: tuple(v.shape) for k, v in module.state_dict().items()}
+
+
+def assert_close(got, ref, tol=2e-4):
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+def mirrored(kind):
+    """The product's parameter-holder classes, built on the meta device (shapes only)."""
+    from src.models import attention, motion_module, resnet, unet
+    with torch.device("meta"):
+        if kind == "resnet_64_128":
+            return resnet.ResnetBlock3D(in_channels=64, out_channels=128, temb_channels=256, eps=1e-5, groups=32,
+                                        non_linearity="silu", use_inflated_groupnorm=False)
+        if kind == "resnet_64_64":
+            return resnet.ResnetBlock3D(in_channels=64, out_channels=64, temb_channels=256, eps=1e-5, groups=32,
+                                        non_linearity="silu", use_inflated_groupnorm=False)
+        if kind == "transformer_64":
+            return attention.Transformer3DModel(8, 8, in_channels=64, num_layers=1, cross_attention_dim=64,
+                                                norm_num_groups=32, unet_use_cross_frame_attention=False,
+                                                unet_use_temporal_attention=False)
+        if kind == "motion_64":
+            return motion_module.VanillaTemporalModule(in_channels=64, **MOTION_KW)
+        if kind == "downsample_64":
+            return resnet.Downsample3D(64, use_conv=True, out_channels=64, padding=1, name="op")
+        if kind == "upsample_64":
+            return resnet.Upsample3D(64, use_conv=True, out_channels=64)
+        if kind == "conv_in_9_64":
+            return resnet.InflatedConv3d(9, 64, kernel_size=3, padding=(1, 1))
+        if kind == "unet_tiny":
+            return unet.UNet3DConditionModel(in_channels=9, cross_attention_dim=64,
+                                             block_out_channels=(64, 128, 256, 256), **UNET_KW)
+        if kind == "unet_full":
+            return unet.UNet3DConditionModel(in_channels=9, cross_attention_dim=768, **UNET_KW)
+    raise KeyError(kind)
+
+
+SEEDS = {"resnet_64_128": 1, "resnet_64_64": 1, "transformer_64": 2, "motion_64": 3, "downsample_64": 4,
+         "upsample_64": 5, "conv_in_9_64": 6, "unet_tiny": 7, "unet_full": 0}
+
+
+def weights(kind):
+    m = mirrored(kind)
+    return synth.procedural_state_dict(shapes_of(m), SEEDS[kind])
+
+
+@pytest.mark.parametrize("kind", ["resnet_64_128", "resnet_64_64", "transformer_64", "motion_64", "downsample_64",
+                                  "upsample_64", "conv_in_9_64"])
+def test_block_layout_and_oracle(kind):
+    g = gold(kind)
+    m = mirrored(kind)
+    assert digest(m.state_dict()) == g["digest"], "mirrored class's state-dict keys/shapes differ from the reference's"
+    sd = weights(kind)
+    x = g["x"]
+    if kind.startswith("resnet"):
+        y = O.resnet_block(sd, "", x, g["temb"], 32, 1e-5)
+    elif kind == "transformer_64":
+        y = O.spatial_transformer(sd, "", x, g["ctx"], 8, 32)
+    elif kind == "motion_64":
+        y = O.motion_module(sd, "", x, 8, 32, 2)
+    elif kind == "downsample_64":
+        y = O.downsample(sd, "", x)
+    elif kind == "upsample_64":
+        y = O.upsample(sd, "", x)
+    else:
+        y = O.conv_frames(x, sd["weight"], sd["bias"])
+    assert_close(y, g["y"])
+
+
+def test_unet_layout_matches_reference_1286_keys():
+    m = mirrored("unet_full")
+    sd = m.state_dict()
+    assert len(sd) == 1286
+    path = os.path.join(GOLD, "unet_full_32.npz")
+    if os.path.exists(path):
+        assert digest(sd) == gold("unet_full_32")["digest"]
+    t = mirrored("unet_tiny")
+    assert digest(t.state_dict()) == gold("unet_tiny_16")["digest"]
+
+
+@pytest.mark.parametrize("name", ["unet_tiny_16", "unet_tiny_32", "unet_tiny_16_tvec"])
+def test_tiny_unet_oracle(name):
+    g = gold(name)
+    sd = weights("unet_tiny")
+    cfg = O.tiny_config(width=64, cross_dim=64, layers_per_block=2)
+    t = g["t"] if torch.is_tensor(g["t"]) else torch.tensor(g["t"])
+    y = O.unet_forward(sd, cfg, g["x"], t, g["ctx"])
+    assert_close(y, g["y"])
+
+
+def test_frames_are_coupled_and_batch_is_not():
+    """perturbing one frame changes the others (cross-frame GroupNorm + temporal attention);
+    perturbing one batch element leaves the other bit-identical."""
+    g = gold("unet_tiny_16")
+    sd = weights("unet_tiny")
+    cfg = O.tiny_config(width=64, cross_dim=64, layers_per_block=2)
+    x = g["x"].clone()
+    base = O.unet_forward(sd, cfg, x, torch.tensor(981), g["ctx"])
+    x2 = x.clone(); x2[0, :, 4] += 0.5
+    pert = O.unet_forward(sd, cfg, x2, torch.tensor(981), g["ctx"])
+    assert (pert[0, :, 0] - base[0, :, 0]).abs().max() > 1e-4
+    assert torch.equal(pert[1], base[1])
+
+
+@pytest.mark.slow
+def test_full_unet_oracle_32():
+    """Full-width restatement vs the reference's full-width output at 32x32 latents (~20 s on 8 cores)."""
+    path = os.path.join(GOLD, "unet_full_32.npz")
+    if not os.path.exists(path):
+        pytest.skip("full-width fixture not generated")
+    g = gold("unet_full_32")
+    sd = weights("unet_full")
+    s = synth.synthetic_story(stories=1, latent_hw=(32, 32), ctx_len=85, seed=42)
+    x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1)
+    with torch.no_grad():
+        y = O.unet_forward(sd, O.SD15_STAGE2_CONFIG, x, torch.tensor(g["t"]), s["ctx"])
+    assert_close(y, g["y"], tol=5e-4)
