@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py — story-frames/sec of the stage-2 denoising hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): PororoSV stage-2, 512x512 (64x64 latents), 50-step DDIM, CFG (guidance 2.0),
+batch = 1 story x 5 frames per GPU, context 85 x 768, synthetic inputs + random-init weights of the real
+1276.9 M-parameter architecture (no checkpoints/datasets exist here).  A "step" is ONE pass of the hot path over
+one batch: the full T-step denoising of `--stories` stories = T x [UNet (b = 2 S) + CFG + DDIM], inputs resident
+in HBM.  N > 1: one process per GPU (torch.distributed / RCCL), stories sharded one batch per rank, NO collective
+in the data path (stories are independent: SURVEY §8e) -> weak scaling; value = all ranks' frames / max-rank time.
+
+Prints ONE JSON line (rank 0).  `roofline`: bound = mfma; one "launch" = one replay of the captured step graph
+(~1.4k kernels = one UNet call + CFG/DDIM); achieved = 11.044 TFLOP algorithmic (SURVEY §8d, 2*MAC of the
+reference's conv/addmm/mm/bmm/baddbmm at b=2,f=5,64x64,L=85) x S / the average replay duration measured with HIP
+events on the launch stream.  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
+timed on this box's host cores on a bounded sample (a few UNet calls of the 50), extrapolated to T calls."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_TFLOP_PER_CALL = {64: 11.044, 32: 2.556}  # per UNet call at b=2 (one story with CFG), L=85  [SURVEY §8d]
+MFMA_F16_PEAK_TFLOPS = 2500.0                  # MI355X dense fp16, MI355X_MICROARCH.md
+
+
+def init_weights_(model, seed=0):
+    """Random init ON the GPU of the real architecture: unit-gain N(0, 1/fan_in) matrices, norms ~ 1, small biases."""
+    from rcdms_amd.synth import _is_norm_param, sinusoid_table
+    g = torch.Generator(device=model.device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.state_dict().items():
+            if name.endswith("pos_encoder.pe"):
+                p.copy_(sinusoid_table(p.shape[2], p.shape[1]))
+            elif p.dim() == 1:
+                is_norm_w = name.endswith(".weight") and _is_norm_param(name)
+                p.normal_(0, 1, generator=g)
+                p.mul_(0.1 if is_norm_w else 0.05)
+                if is_norm_w:
+                    p.add_(1.0)
+            else:
+                fan_in = p[0].numel()
+                p.normal_(0, fan_in ** -0.5, generator=g)
+
+
+def build_model(device):
+    from src.models.unet import UNet3DConditionModel
+    mk = dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
+              temporal_position_encoding=True, temporal_position_encoding_max_len=5, temporal_attention_dim_div=1)
+    with torch.device("meta"):
+        m = UNet3DConditionModel(sample_size=64, in_channels=9, cross_attention_dim=768, use_motion_module=True,
+                                 motion_module_resolutions=[1, 2, 4, 8], unet_use_cross_frame_attention=False,
+                                 unet_use_temporal_attention=False, motion_module_type="Vanilla",
+                                 motion_module_kwargs=mk)
+    m = m.to_empty(device=device).eval()
+    init_weights_(m)
+    return m
+
+
+def cpu_baseline(model, story, latent, ddim_steps, budget_s=30.0):
+    """Oracle (CPU fp32 restatement of the reference) on the host cores: median of up to 3 UNet calls within the
+    budget (always at least one), extrapolated to T calls per story."""
+    from oracle import unet_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    x = torch.cat([torch.cat([story["latents"]] * 2), story["mask"], story["masked_latents"]], dim=1)
+    times = []
+    t_start = time.time()
+    with torch.no_grad():
+        while len(times) < 3 and (not times or (time.time() - t_start) + times[-1] < budget_s):
+            t0 = time.time()
+            O.unet_forward(sd, O.SD15_STAGE2_CONFIG, x, torch.tensor(981), story["ctx"])
+            times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    fps = 5.0 / (ddim_steps * med)
+    return {"value": fps, "unit": "story-frames/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} UNet call(s) of the {ddim_steps} per story at {latent}x{latent} latents, b=2 f=5 L=85, "
+                      f"fp32 torch CPU restatement; median {med:.2f} s/call, extrapolated x{ddim_steps}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed passes (each = one full T-step story batch)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--stories", type=int, default=1, help="stories per GPU per pass (batch)")
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--ctx-len", type=int, default=85)
+    ap.add_argument("--guidance", type=float, default=2.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__
+    __graft_entry__.build()
+    from rcdms_amd import hip, synth
+    from rcdms_amd.sampler import DenoiseLoop
+    from rcdms_amd.scheduler import DDIMScheduler
+
+    model = build_model(dev)
+    if dist_on:
+        from rcdms_amd.dist import broadcast_module
+        broadcast_module(model, src=0)  # RCCL over xGMI: every replica holds rank 0's weights
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    S, T = a.stories, a.ddim_steps
+    story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42 + rank)
+    loop = DenoiseLoop(model, S, 5, a.latent, a.latent, a.ctx_len, a.guidance, sched, T)
+
+    def one_pass():
+        loop.load(story["latents"], story["mask"], story["masked_latents"], story["ctx"])
+        loop.run(use_graph=not a.no_graph)
+
+    for _ in range(a.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+
+    # timed region: inputs are re-staged (a few MB H2D) inside load(); the loop itself is K x T graph replays
+    ev0, ev1 = hip.Event(), hip.Event()
+    gpu_ms = 0.0
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loop.load(story["latents"], story["mask"], story["masked_latents"], story["ctx"])
+        sp = loop.prog.stream.cuda_stream
+        ev0.record(sp)
+        loop.run(use_graph=not a.no_graph)
+        ev1.record(sp)
+        gpu_ms += ev0.elapsed_ms(ev1)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    frames = 5 * S * a.steps * world
+    value = frames / dt
+    launches = a.steps * T
+    avg_launch_ms = gpu_ms / launches
+    tf_call = ALGO_TFLOP_PER_CALL.get(a.latent)
+    roof = None
+    if tf_call is not None:
+        achieved = tf_call * S / (avg_launch_ms * 1e-3)
+        roof = {"bound": "mfma", "kernel": "denoise-step graph (UNet b=%d + CFG + DDIM)" % (2 * S if a.guidance > 1 else S),
+                "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches}
+
+    out = {
+        "metric": "story-frames/sec (stage-2 UNet, 50-step DDIM, 512^2)", "value": round(value, 4),
+        "unit": "story-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"PororoSV stage-2, {a.latent * 8}x{a.latent * 8}, {T}-step DDIM, CFG {a.guidance}, "
+                               f"batch={S} story x 5 frames per GPU, ctx {a.ctx_len}x768, random-init 1276.9M-param UNet3D",
+                   "stories_per_gpu": S, "latent": a.latent, "ddim_steps": T, "parallelism": f"story-replicas x{world}"},
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        s1 = synth.synthetic_story(stories=1, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42)
+        out["cpu_baseline"] = cpu_baseline(model, s1, a.latent, T)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
