@@ -98,67 +98,80 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   const int ks_end = min(p.nk, ks_begin + p.nk_per_split);
 
   // ---- loader state: thread owns 16-B chunk cc of rows r0 + 32 j -------------------------------
+  // All global reads are raw buffer loads: a lane whose row / tap / channel chunk is out of range gets
+  // the offset 0x80000000 (>= num_records) and the hardware returns zeros — no branches, no scratch.
   const int cc = t & 7, r0 = t >> 3;
-  size_t a_base[4];  // TAPS==1: row offset; TAPS==9: image base pixel index * lda (unused)
-  int a_img[4], a_iy0[4], a_ix0[4];
-  bool a_ok[4], w_ok[4];
-  size_t w_off[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + r0 + 32 * j;
-    a_ok[j] = m < p.M;
-    if (TAPS == 1) {
-      a_base[j] = (size_t)m * p.lda;
-      a_img[j] = a_iy0[j] = a_ix0[j] = 0;
-    } else {
-      const int hw = p.Ho * p.Wo;
-      const int img = m / hw, rem = m - img * hw;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_img[j] = img;
-      a_iy0[j] = oy * p.stride - 1;
-      a_ix0[j] = ox * p.stride - 1;
-      a_base[j] = 0;
-    }
-    const int n = n0 + r0 + 32 * j;
-    w_ok[j] = n < p.N;
-    w_off[j] = (size_t)n * p.Ktot;
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7FFFFFFF, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_off0, a_off1, a_off2, a_off3;      // TAPS==1: byte offset of the row
+  int a_img0, a_img1, a_img2, a_img3, a_iy0, a_iy1, a_iy2, a_iy3, a_ix0, a_ix1, a_ix2, a_ix3;
+  unsigned w_off0, w_off1, w_off2, w_off3;
+#define ROW_SETUP(J)                                                              \
+  {                                                                               \
+    const int m = m0 + r0 + 32 * J;                                               \
+    a_img##J = a_iy##J = a_ix##J = 0;                                             \
+    a_off##J = OOB;                                                               \
+    if (TAPS == 1) {                                                              \
+      if (m < p.M) a_off##J = (unsigned)m * (unsigned)p.lda * 2u;                 \
+    } else {                                                                      \
+      const int hw = p.Ho * p.Wo;                                                 \
+      const int img = m / hw, rem = m - img * hw;                                 \
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;                            \
+      a_img##J = img;                                                             \
+      a_iy##J = m < p.M ? oy * p.stride - 1 : -(1 << 20);                         \
+      a_ix##J = ox * p.stride - 1;                                                \
+    }                                                                             \
+    const int n = n0 + r0 + 32 * J;                                               \
+    w_off##J = n < p.N ? (unsigned)n * (unsigned)p.Ktot * 2u : OOB;               \
   }
+  ROW_SETUP(0) ROW_SETUP(1) ROW_SETUP(2) ROW_SETUP(3)
+#undef ROW_SETUP
   const int Hv = p.Hi << p.up, Wv = p.Wi << p.up;
 
-  auto load_tile = [&](int ks, uint4 (&ra)[4], uint4 (&rb)[4]) {
-    int tap = 0, kci = ks;
-    if (TAPS != 1) {
-      tap = ks / p.kc;
-      kci = ks - tap * p.kc;
-    }
-    const int c = kci * BK + cc * 8;
-    const bool c_ok = c < p.Cin;
-    const int dy = tap / 3, dx = tap - dy * 3;
-    const uint4 zero = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bool ok = c_ok && a_ok[j];
-      const f16* src;
-      if (TAPS == 1) {
-        src = p.A + a_base[j] + c;
-      } else {
-        const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
-        ok = ok && ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
-        const int sy = iy >> p.up, sx = ix >> p.up;
-        src = p.A + ((size_t)((a_img[j] * p.Hi + sy) * p.Wi + sx)) * p.lda + c;
-      }
-      ra[j] = ok ? *(const uint4*)src : zero;
-      rb[j] = (c_ok && w_ok[j]) ? *(const uint4*)(p.W + w_off[j] + (size_t)tap * p.Cin + c) : zero;
-    }
-  };
-  auto store_tile = [&](int buf, const uint4 (&ra)[4], const uint4 (&rb)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int off = buf * BM * PITCH + (r0 + 32 * j) * PITCH + cc * 8;
-      *(uint4*)(sA + off) = ra[j];
-      *(uint4*)(sB + off) = rb[j];
-    }
-  };
+  u32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define LOAD_ROW(J, tap, c, c_ok, dy, dx)                                                                  \
+  {                                                                                                        \
+    unsigned ao;                                                                                           \
+    if (TAPS == 1) {                                                                                       \
+      ao = (c_ok && a_off##J != OOB) ? a_off##J + (unsigned)(c)*2u : OOB;                                  \
+    } else {                                                                                               \
+      const int iy = a_iy##J + dy, ix = a_ix##J + dx;                                                      \
+      const bool ok = c_ok && ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);              \
+      const int sy = iy >> p.up, sx = ix >> p.up;                                                          \
+      ao = ok ? ((unsigned)((a_img##J * p.Hi + sy) * p.Wi + sx) * (unsigned)p.lda + (unsigned)(c)) * 2u : OOB; \
+    }                                                                                                      \
+    ra##J = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, ao, 0, 0);                                        \
+    const unsigned wo = (c_ok && w_off##J != OOB) ? w_off##J + ((unsigned)(tap) * (unsigned)p.Cin + (unsigned)(c)) * 2u : OOB; \
+    rb##J = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, wo, 0, 0);                                        \
+  }
+#define LOAD_TILE(ks)                                     \
+  {                                                       \
+    int tap = 0, kci = (ks);                              \
+    if (TAPS != 1) {                                      \
+      tap = (ks) / p.kc;                                  \
+      kci = (ks)-tap * p.kc;                              \
+    }                                                     \
+    const int c = kci * BK + cc * 8;                      \
+    const bool c_ok = c < p.Cin;                          \
+    const int dy = tap / 3, dx = tap - dy * 3;            \
+    LOAD_ROW(0, tap, c, c_ok, dy, dx)                     \
+    LOAD_ROW(1, tap, c, c_ok, dy, dx)                     \
+    LOAD_ROW(2, tap, c, c_ok, dy, dx)                     \
+    LOAD_ROW(3, tap, c, c_ok, dy, dx)                     \
+  }
+#define STORE_TILE(buf)                                                     \
+  {                                                                         \
+    const int off = (buf)*BM * PITCH + r0 * PITCH + cc * 8;                 \
+    *(u32x4*)(sA + off) = ra0;                                              \
+    *(u32x4*)(sB + off) = rb0;                                              \
+    *(u32x4*)(sA + off + 32 * PITCH) = ra1;                                 \
+    *(u32x4*)(sB + off + 32 * PITCH) = rb1;                                 \
+    *(u32x4*)(sA + off + 64 * PITCH) = ra2;                                 \
+    *(u32x4*)(sB + off + 64 * PITCH) = rb2;                                 \
+    *(u32x4*)(sA + off + 96 * PITCH) = ra3;                                 \
+    *(u32x4*)(sB + off + 96 * PITCH) = rb3;                                 \
+  }
 
   // ---- main loop -------------------------------------------------------------------------------
   const int wm = wave >> 1, wn = wave & 1;
@@ -171,16 +184,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  uint4 ra[4], rb[4];
   if (ks_begin < ks_end) {
-    load_tile(ks_begin, ra, rb);
-    store_tile(0, ra, rb);
+    LOAD_TILE(ks_begin)
+    STORE_TILE(0)
   }
   __syncthreads();
   for (int ks = ks_begin; ks < ks_end; ++ks) {
     const int buf = (ks - ks_begin) & 1;
     const bool more = ks + 1 < ks_end;
-    if (more) load_tile(ks + 1, ra, rb);  // global loads in flight under the MFMAs below
+    if (more) LOAD_TILE(ks + 1)  // global loads in flight under the MFMAs below
     const f16* bA = sA + buf * BM * PITCH + (wm * 64 + lr) * PITCH + hi * 8;
     const f16* bB = sB + buf * BM * PITCH + (wn * 64 + lr) * PITCH + hi * 8;
 #pragma unroll
@@ -196,10 +208,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(buf ^ 1, ra, rb);
+    if (more) STORE_TILE(buf ^ 1)
     __syncthreads();
   }
 
+#undef LOAD_ROW
+#undef LOAD_TILE
+#undef STORE_TILE
   // ---- stage the fp32 tile through LDS: sC[pixel][channel] -------------------------------------
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -331,6 +346,9 @@ int check_common(const IgemmArgs& a) {
   if ((a.epi & RCDM_EPI_ROWVEC) && (!a.rowvec || a.rows_per_sample <= 0)) return RCDM_EINVAL;
   if ((a.epi & RCDM_EPI_RESIDUAL) && (!a.res || (a.ldr & 7))) return RCDM_EINVAL;
   if ((a.epi & RCDM_EPI_GEGLU) && (a.N % 128)) return RCDM_ESHAPE;
+  // buffer-load offsets are 32-bit with 0x80000000 reserved as "out of range"
+  const size_t in_rows = (a.Ktot == a.Cin) ? (size_t)a.M : (size_t)(a.M / (a.Ho * a.Wo)) * a.Hi * a.Wi;
+  if (in_rows * (size_t)a.lda * 2 >= 0x7FFFFFFFull || (size_t)a.N * a.Ktot * 2 >= 0x7FFFFFFFull) return RCDM_ESHAPE;
   return RCDM_OK;
 }
 
