@@ -65,6 +65,10 @@ typedef struct {
 } rcdm_gemm_desc;
 
 size_t rcdm_gemm_workspace_bytes(const rcdm_gemm_desc* d);
+/* tuning/test knob for rcdm_gemm and rcdm_conv3x3: -1 = automatic (default; env RCDM_IGEMM=legacy|dma128|dma256
+ * overrides), 0 = register-staged 128x128 tile, 1 = LDS-DMA 128x128 2-stage, 2 = LDS-DMA 256x128 3-stage.
+ * Changes the workspace size a shape needs: query rcdm_*_workspace_bytes after setting it. */
+int rcdm_set_igemm_variant(int32_t variant);
 int rcdm_gemm(const rcdm_gemm_desc* d, const void* A, const void* W, const float* bias,
               const float* rowvec, const void* residual, void* out, void* workspace,
               size_t workspace_bytes, void* stream);

@@ -69,25 +69,43 @@ __global__ void gn_stats_kernel(const GnArgs p) {
   }
 }
 
-// one thread per (sample, group): Chan's pairwise combination in split order.
-__global__ void gn_finalize_kernel(const GnArgs p) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per (sample, group): lanes take splits lane, lane+64, ... in order, then a fixed xor-butterfly
+// of Chan's pairwise combination — deterministic (the tree shape never changes), no atomics.
+__device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float qb) {
+  const float nt = n + nb;
+  if (nt > 0.f) {
+    const float delta = mb - mean;
+    const float f = nb / nt;
+    mean += delta * f;
+    m2 += qb + delta * delta * n * f;
+    n = nt;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (idx >= p.samples * p.G) return;
   const int s = idx / p.G, g = idx - s * p.G;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int sp = 0; sp < p.splits; ++sp) {
+  for (int sp = lane; sp < p.splits; sp += 64) {
     const float* o = p.partial + (((size_t)s * p.splits + sp) * p.G + g) * 3;
-    const float nb = o[0], mb = o[1], qb = o[2];
-    if (nb > 0.f) {
-      const float nt = n + nb, delta = mb - mean;
-      mean += delta * (nb / nt);
-      m2 += qb + delta * delta * (n * nb / nt);
-      n = nt;
-    }
+    chan_combine(n, mean, m2, o[0], o[1], o[2]);
   }
-  const float var = n > 0.f ? m2 / n : 0.f;  // biased, as torch.nn.GroupNorm
-  p.stat[idx * 2] = mean;
-  p.stat[idx * 2 + 1] = rsqrtf(var + p.eps);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float nb = __shfl_xor(n, off, 64), mb = __shfl_xor(mean, off, 64), qb = __shfl_xor(m2, off, 64);
+    // combine in a lane-order-independent way: the lower lane of each pair is always the "left" operand
+    float ln = n, lm = mean, lq = m2, rn = nb, rm = mb, rq = qb;
+    if (lane & off) { ln = nb; lm = mb; lq = qb; rn = n; rm = mean; rq = m2; }
+    chan_combine(ln, lm, lq, rn, rm, rq);
+    n = ln; mean = lm; m2 = lq;
+  }
+  if (lane == 0) {
+    const float var = n > 0.f ? m2 / n : 0.f;  // biased, as torch.nn.GroupNorm
+    p.stat[idx * 2] = mean;
+    p.stat[idx * 2 + 1] = rsqrtf(var + p.eps);
+  }
 }
 
 // grid (blocks_per_sample, samples); same thread->chunk mapping as the stats kernel.
@@ -141,62 +159,79 @@ int gn_plan(const rcdm_groupnorm_desc* d, GnArgs& a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, the row held in registers (NCH 16-B chunks per lane), exact two-pass.
-template <int NCH>
+// LayerNorm: a wave normalises R rows at a time (all R*NCH 16-byte loads issued before the first
+// reduction, so one wave keeps several KB in flight); each row is held in registers, exact two-pass.
+template <int NCH, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, f16* __restrict__ y,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         const float* __restrict__ pe, int M, int C, int ldx,
                                                         int ldy, float eps, int rows_per_frame, int frames) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
   const int nchunks = C >> 3;
-  float v[NCH][8];
-  float sum = 0.f;
+  Pack16 raw[R][NCH];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      raw[r][i].u = make_uint4(0, 0, 0, 0);
+      if (c < nchunks && row0 + r < M) raw[r][i].u = *(const uint4*)(x + (size_t)(row0 + r) * ldx + c * 8);
+    }
+  float gm[NCH][8], bt[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    if (c < nchunks) {
-      Pack16 pk;
-      pk.u = *(const uint4*)(x + (size_t)row * ldx + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gm[i][e] = c < nchunks ? gamma[c * 8 + e] : 0.f;
+      bt[i][e] = c < nchunks ? beta[c * 8 + e] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = row0 + r;
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        v[i][e] = (float)pk.e[e];
+        v[i][e] = (float)raw[r][i].e[e];
         sum += v[i][e];
       }
-    } else {
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-    }
-  }
-  const float mean = wave_sum(sum) / (float)C;
-  float sq = 0.f;
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunks) {
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunks) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float dlt = v[i][e] - mean;
-        sq += dlt * dlt;
+        for (int e = 0; e < 8; ++e) {
+          const float dlt = v[i][e] - mean;
+          sq += dlt * dlt;
+        }
       }
     }
-  }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-  const float* pe_row = pe ? pe + (size_t)((row / rows_per_frame) % frames) * C : nullptr;
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    if (row < M) {
+      const float* pe_row = pe ? pe + (size_t)((row / rows_per_frame) % frames) * C : nullptr;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunks) {
-      Pack16 o;
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunks) {
+          Pack16 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float f = (v[i][e] - mean) * rstd * gamma[c * 8 + e] + beta[c * 8 + e];
-        if (pe_row) f += pe_row[c * 8 + e];
-        o.e[e] = (f16)f;
+          for (int e = 0; e < 8; ++e) {
+            float f = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+            if (pe_row) f += pe_row[c * 8 + e];
+            o.e[e] = (f16)f;
+          }
+          *(uint4*)(y + (size_t)row * ldy + c * 8) = o.u;
+        }
       }
-      *(uint4*)(y + (size_t)row * ldy + c * 8) = o.u;
     }
   }
 }
@@ -229,7 +264,7 @@ int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float
   rc = rcdm_check_launch();
   if (rc) return rc;
   const int nsg = a.samples * a.G;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 63) / 64), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, stream, a);
   rc = rcdm_check_launch();
   if (rc) return rc;
   int bps = (a.P + a.RPB * 8 - 1) / (a.RPB * 8);  // ~8 rows per thread
@@ -248,16 +283,16 @@ int rcdm_layernorm(const rcdm_layernorm_desc* d, const void* x, const float* gam
   if (pe && (d->rows_per_frame <= 0 || d->frames <= 0)) return RCDM_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   const int nch = ((d->C >> 3) + 63) / 64;
-  dim3 grid((d->M + 3) / 4), block(256);
+  dim3 block(256);
   const int rpf = pe ? d->rows_per_frame : 1, fr = pe ? d->frames : 1;
-#define LN_LAUNCH(N)                                                                                       \
-  hipLaunchKernelGGL(layernorm_kernel<N>, grid, block, 0, stream, (const f16*)x, (f16*)y, gamma, beta, pe, \
-                     d->M, d->C, d->ldx, d->ldy, d->eps, rpf, fr)
+#define LN_LAUNCH(N, R)                                                                                      \
+  hipLaunchKernelGGL((layernorm_kernel<N, R>), dim3((d->M + 4 * R - 1) / (4 * R)), block, 0, stream,        \
+                     (const f16*)x, (f16*)y, gamma, beta, pe, d->M, d->C, d->ldx, d->ldy, d->eps, rpf, fr)
   switch (nch) {
-    case 1: LN_LAUNCH(1); break;
-    case 2: LN_LAUNCH(2); break;
-    case 3: LN_LAUNCH(3); break;
-    default: LN_LAUNCH(4); break;
+    case 1: LN_LAUNCH(1, 4); break;
+    case 2: LN_LAUNCH(2, 2); break;
+    case 3: LN_LAUNCH(3, 2); break;
+    default: LN_LAUNCH(4, 1); break;
   }
 #undef LN_LAUNCH
   return rcdm_check_launch();

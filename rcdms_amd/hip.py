@@ -63,6 +63,7 @@ SYMBOLS = {
     "rcdm_last_hip_error": (C.c_int, []),
     "rcdm_last_hip_error_string": (C.c_char_p, []),
     "rcdm_gemm_workspace_bytes": (_SZ, [C.POINTER(GemmDesc)]),
+    "rcdm_set_igemm_variant": (C.c_int, [_I]),
     "rcdm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_conv3x3_workspace_bytes": (_SZ, [C.POINTER(ConvDesc)]),
     "rcdm_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -133,6 +134,10 @@ def ptr(t):
 
 # ------------------------------------------------------------------------------------------------
 # thin typed wrappers (all enqueue on torch's current stream unless `stream` is given)
+
+def set_igemm_variant(v):
+    _check(load().rcdm_set_igemm_variant(v), "rcdm_set_igemm_variant")
+
 
 def gemm_workspace_bytes(desc):
     return load().rcdm_gemm_workspace_bytes(C.byref(desc))

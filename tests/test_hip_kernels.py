@@ -59,8 +59,10 @@ def ws(nbytes):
     (130, 72, 200, 1 | 4, 3),        # forced split-K, K tail (200 = 3*64 + 8), N % 128 != 0
     (1024, 960, 320, 0, 1),
 ])
-def test_gemm(hiplib, M, N, K, epi, split):
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_gemm(hiplib, M, N, K, epi, split, variant):
     from rcdms_amd import hip
+    hip.set_igemm_variant(variant)
     g = torch.Generator().manual_seed(1234 + M + N + K)
     A = h16(torch.randn(M, K, generator=g))
     W = h16(torch.randn(N, K, generator=g) * K ** -0.5)
@@ -86,6 +88,7 @@ def test_gemm(hiplib, M, N, K, epi, split):
     hip.gemm(d, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), rvd.data_ptr(), Rd.data_ptr(), out.data_ptr(),
              w.data_ptr(), w.numel())
     torch.cuda.synchronize()
+    hip.set_igemm_variant(-1)
     close(out[:, :N], ref)
     assert torch.isnan(out[:, N:].float()).all(), "wrote outside the N columns"
 
@@ -105,9 +108,11 @@ def test_gemm_transpose_detecting(hiplib):
     close(out, W.t(), rel=1e-3, abs_frac=1e-3)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("split", [1, 2])
-def test_gemm_geglu(hiplib, split):
+def test_gemm_geglu(hiplib, split, variant):
     from rcdms_amd import hip
+    hip.set_igemm_variant(variant)
     g = torch.Generator().manual_seed(7)
     M, C = 200, 64
     x = h16(torch.randn(M, C, generator=g))
@@ -125,6 +130,7 @@ def test_gemm_geglu(hiplib, split):
     w = ws(hip.gemm_workspace_bytes(d))
     hip.gemm(d, xd.data_ptr(), wp.data_ptr(), bp.data_ptr(), 0, 0, out.data_ptr(), w.data_ptr(), w.numel())
     torch.cuda.synchronize()
+    hip.set_igemm_variant(-1)
     close(out, ref)
 
 
@@ -135,8 +141,10 @@ def test_gemm_geglu(hiplib, split):
     (1, 5, 8, 8, 128, 64, 1, 1, 1),     # Upsample3D folded into the conv
     (2, 1, 8, 8, 320, 320, 1, 0, 4),    # split-K
 ])
-def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split):
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split, variant):
     from rcdms_amd import hip
+    hip.set_igemm_variant(variant)
     g = torch.Generator().manual_seed(99 + cin + cout + stride + up)
     x = h16(torch.randn(b, cin, f, H, W, generator=g))
     w = h16(torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
@@ -161,6 +169,7 @@ def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split):
     hip.conv3x3(d, xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), td.data_ptr(), rd.data_ptr(), out.data_ptr(),
                 wsb.data_ptr(), wsb.numel())
     torch.cuda.synchronize()
+    hip.set_igemm_variant(-1)
     close(rows_to_5d(out, b, cout, f, Ho, Wo), ref)
 
 

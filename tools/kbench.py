@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single librcdm_hip kernels at the UNet's hot shapes (HIP-event timed, interleaved rounds).
+usage: python tools/kbench.py [gemm|conv|attn|norm|all] [--variants 0,1,2] [--rounds 5]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rcdms_amd import hip  # noqa: E402
+
+DEV = "cuda"
+
+
+def timeit(fn, rounds=5, inner=10):
+    fn()
+    torch.cuda.synchronize()
+    best = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best.append(e0.elapsed_time(e1) / inner * 1e3)
+    best.sort()
+    return best[len(best) // 2], best[0]
+
+
+GEMMS = [  # (name, M, N, K, epi)
+    ("L0 CxC K=320 +bias+res", 40960, 320, 320, 5),
+    ("L0 qkv N=960", 40960, 960, 320, 0),
+    ("L0 geglu N=2560", 40960, 2560, 320, 9),
+    ("L0 ff-out K=1280", 40960, 320, 1280, 5),
+    ("L1 CxC K=640", 10240, 640, 640, 5),
+    ("L1 geglu N=5120", 10240, 5120, 640, 9),
+    ("L1 ff-out K=2560", 10240, 640, 2560, 5),
+    ("L2 CxC K=1280", 2560, 1280, 1280, 5),
+    ("L2 geglu N=10240", 2560, 10240, 1280, 9),
+    ("L2 ff-out K=5120", 2560, 1280, 5120, 5),
+]
+CONVS = [  # (name, n_img, H, W, cin, cout)
+    ("L0 320->320 @64", 10, 64, 64, 320, 320),
+    ("L0 960->320 @64", 10, 64, 64, 960, 320),
+    ("L1 640->640 @32", 10, 32, 32, 640, 640),
+    ("L1 1920->640 @32", 10, 32, 32, 1920, 640),
+    ("L2 1280->1280 @16", 10, 16, 16, 1280, 1280),
+    ("L3 1280->1280 @8", 10, 8, 8, 1280, 1280),
+    ("L3 2560->1280 @8", 10, 8, 8, 2560, 1280),
+]
+
+
+def bench_gemm(variants, rounds):
+    for name, M, N, K, epi in GEMMS:
+        A = torch.randn(M, K, device=DEV).half()
+        W = (torch.randn(N, K, device=DEV) * K ** -0.5).half()
+        bias = torch.randn(N, device=DEV)
+        nout = N // 2 if epi & 8 else N
+        res = torch.randn(M, nout, device=DEV).half()
+        out = torch.empty(M, nout, device=DEV, dtype=torch.float16)
+        line = f"gemm {name:28s} {2.0 * M * N * K / 1e9:8.1f} GF |"
+        for v in variants:
+            hip.set_igemm_variant(v)
+            d = hip.GemmDesc(M, N, K, K, nout, nout, epi, 1, 0, 1.0, 0)
+            wsb = hip.gemm_workspace_bytes(d)
+            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+            fn = lambda: hip.gemm(d, A.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, res.data_ptr(), out.data_ptr(),
+                                  ws.data_ptr(), ws.numel())
+            med, mn = timeit(fn, rounds)
+            line += f" v{v}: {med:7.1f}us {2.0 * M * N * K / med / 1e6:6.0f}TF |"
+        print(line, flush=True)
+    hip.set_igemm_variant(-1)
+
+
+def bench_conv(variants, rounds):
+    for name, n, H, W, cin, cout in CONVS:
+        x = torch.randn(n * H * W, cin, device=DEV).half()
+        w = (torch.randn(cout, 9 * cin, device=DEV) * (9 * cin) ** -0.5).half()
+        bias = torch.randn(cout, device=DEV)
+        out = torch.empty(n * H * W, cout, device=DEV, dtype=torch.float16)
+        fl = 2.0 * n * H * W * 9 * cin * cout
+        line = f"conv {name:28s} {fl / 1e9:8.1f} GF |"
+        for v in variants:
+            hip.set_igemm_variant(v)
+            d = hip.ConvDesc(n, H, W, cin, cout, 1, 0, cin, cout, 0, 1, 1, 0, 1.0, 0)
+            wsb = hip.conv3x3_workspace_bytes(d)
+            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+            fn = lambda: hip.conv3x3(d, x.data_ptr(), w.data_ptr(), bias.data_ptr(), 0, 0, out.data_ptr(), ws.data_ptr(),
+                                     ws.numel())
+            med, mn = timeit(fn, rounds)
+            line += f" v{v}: {med:7.1f}us {fl / med / 1e6:6.0f}TF |"
+        print(line, flush=True)
+    hip.set_igemm_variant(-1)
+
+
+def bench_attn(rounds):
+    for name, batch, heads, L, Lk, d in [("L0 self d=40", 10, 8, 4096, 4096, 40), ("L1 self d=80", 10, 8, 1024, 1024, 80),
+                                          ("L2 self d=160", 10, 8, 256, 256, 160), ("L0 cross Lk=85", 10, 8, 4096, 85, 40)]:
+        C = heads * d
+        qkv = torch.randn(batch * L, 3 * C, device=DEV).half()
+        kv = torch.randn(batch * Lk, 2 * C, device=DEV).half()
+        out = torch.empty(batch * L, C, device=DEV, dtype=torch.float16)
+        if L == Lk:
+            desc = hip.AttnDesc(batch, heads, L, Lk, d, 3 * C, 3 * C, 3 * C, C, d ** -0.5)
+            fn = lambda: hip.flash_attn(desc, qkv.data_ptr(), qkv.data_ptr() + 2 * C, qkv.data_ptr() + 4 * C, out.data_ptr())
+        else:
+            desc = hip.AttnDesc(batch, heads, L, Lk, d, 3 * C, 2 * C, 2 * C, C, d ** -0.5)
+            fn = lambda: hip.flash_attn(desc, qkv.data_ptr(), kv.data_ptr(), kv.data_ptr() + 2 * C, out.data_ptr())
+        med, mn = timeit(fn, rounds)
+        fl = 4.0 * batch * heads * L * Lk * d
+        print(f"attn {name:28s} {fl / 1e9:8.1f} GF | {med:7.1f}us {fl / med / 1e6:6.0f}TF", flush=True)
+    for name, b, f, px, heads, d in [("L0 temporal", 2, 5, 4096, 8, 40), ("L1 temporal", 2, 5, 1024, 8, 80)]:
+        C = heads * d
+        qkv = torch.randn(b * f * px, 3 * C, device=DEV).half()
+        out = torch.empty(b * f * px, C, device=DEV, dtype=torch.float16)
+        desc = hip.TemporalAttnDesc(b, f, px, heads, d, 3 * C, C, d ** -0.5)
+        med, mn = timeit(lambda: hip.temporal_attn(desc, qkv.data_ptr(), out.data_ptr()), rounds)
+        by = qkv.numel() * 2 + out.numel() * 2
+        print(f"attn {name:28s} {by / 1e6:8.1f} MB | {med:7.1f}us {by / med / 1e6:6.2f}TB/s", flush=True)
+
+
+def bench_norm(rounds):
+    for name, M, C in [("L0 LN C=320", 40960, 320), ("L1 LN C=640", 10240, 640), ("L2 LN C=1280", 2560, 1280)]:
+        x = torch.randn(M, C, device=DEV).half()
+        y = torch.empty_like(x)
+        g, b = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+        d = hip.LayerNormDesc(M, C, C, C, 1e-5, 1, 1)
+        med, mn = timeit(lambda: hip.layernorm(d, x.data_ptr(), g.data_ptr(), b.data_ptr(), 0, y.data_ptr()), rounds)
+        print(f"norm {name:28s} {4.0 * M * C / 1e6:8.1f} MB | {med:7.1f}us {4.0 * M * C / med / 1e6:6.2f}TB/s", flush=True)
+    for name, smp, rps, C, silu in [("L0 GN cross C=320", 2, 20480, 320, 1), ("L0 GN cross C=960", 2, 20480, 960, 1),
+                                    ("L0 GN frame C=320", 10, 4096, 320, 0), ("L2 GN cross C=1280", 2, 1280, 1280, 1)]:
+        x = torch.randn(smp * rps, C, device=DEV).half()
+        y = torch.empty_like(x)
+        g, b = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+        d = hip.GroupNormDesc(smp, rps, C, 32, C, C, 1e-5, silu)
+        ws = torch.empty(hip.groupnorm_workspace_bytes(d), dtype=torch.uint8, device=DEV)
+        med, mn = timeit(lambda: hip.groupnorm_silu(d, x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                                    ws.numel()), rounds)
+        by = 6.0 * smp * rps * C
+        print(f"norm {name:28s} {by / 1e6:8.1f} MB | {med:7.1f}us {by / med / 1e6:6.2f}TB/s (2 reads + 1 write)", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--variants", default="0,1,2")
+    ap.add_argument("--rounds", type=int, default=5)
+    a = ap.parse_args()
+    vs = [int(v) for v in a.variants.split(",")]
+    if a.what in ("gemm", "all"):
+        bench_gemm(vs, a.rounds)
+    if a.what in ("conv", "all"):
+        bench_conv(vs, a.rounds)
+    if a.what in ("attn", "all"):
+        bench_attn(a.rounds)
+    if a.what in ("norm", "all"):
+        bench_norm(a.rounds)
