@@ -38,8 +38,8 @@ extern "C" {
 #define RCDM_EPI_BIAS 1      /* + bias[n]                              (fp32 [N])                  */
 #define RCDM_EPI_ROWVEC 2    /* + rowvec[m / rows_per_sample][n]       (fp32, resnet.py:191-194)   */
 #define RCDM_EPI_RESIDUAL 4  /* + residual[m][n]                       (f16, ldr)                  */
-#define RCDM_EPI_GEGLU 8     /* out[m][j] = (h+bh) * gelu(g+bg); W/bias rows packed per 128-row    */
-                             /* tile as 64 h rows then their 64 g rows (see rcdm_pack_geglu_rows)  */
+#define RCDM_EPI_GEGLU 8     /* out[m][j] = (h+bh) * gelu(g+bg); W/bias rows packed in groups of   */
+                             /* 64 = 32 hidden rows then their 32 gate rows (rcdm_pack_geglu_rows) */
 
 int rcdm_version(void);
 /* last HIP error code seen by this library on this thread (0 = none) and its string */
@@ -65,8 +65,8 @@ typedef struct {
 } rcdm_gemm_desc;
 
 size_t rcdm_gemm_workspace_bytes(const rcdm_gemm_desc* d);
-/* tuning/test knob for rcdm_gemm and rcdm_conv3x3: -1 = automatic (default; env RCDM_IGEMM=legacy|dma128|dma256
- * overrides), 0 = register-staged 128x128 tile, 1 = LDS-DMA 128x128 2-stage, 2 = LDS-DMA 256x128 3-stage.
+/* tuning/test knob for rcdm_gemm and rcdm_conv3x3: -1 = automatic (default; env RCDM_IGEMM=dma128|dma256|dma320
+ * overrides), 1..3 = 128x128 / 256x256 / 256x320 (pixels x channels) tiles (3 falls back to 2 for GEGLU).
  * Changes the workspace size a shape needs: query rcdm_*_workspace_bytes after setting it. */
 int rcdm_set_igemm_variant(int32_t variant);
 int rcdm_gemm(const rcdm_gemm_desc* d, const void* A, const void* W, const float* bias,
@@ -222,7 +222,8 @@ int rcdm_advance_step(int32_t* step_counter, void* stream);
  *   rcdm_pack_f16: elementwise fp32 -> f16.
  *   rcdm_pack_conv3x3: torch (Cout,Cin,3,3) fp32 -> f16 [Cout][9*cin_pad], k = tap*cin_pad + c.
  *   rcdm_pack_geglu_rows: FeedForward.net.0.proj weight (8C,K)/bias(8C) -> rows reordered so every
- *   128-row tile holds 64 "hidden" rows then the matching 64 "gate" rows (RCDM_EPI_GEGLU).
+ *   64-row group holds 32 "hidden" rows then the matching 32 "gate" rows (RCDM_EPI_GEGLU): the two
+ *   land in adjacent MFMA fragments of the same lane.
  * ---------------------------------------------------------------------------------------------- */
 int rcdm_pack_f16(const float* src, void* dst, size_t n, void* stream);
 int rcdm_pack_conv3x3(const float* w, int32_t c_out, int32_t c_in, int32_t cin_pad, void* dst,

@@ -145,9 +145,13 @@ def bench_norm(rounds):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
-    ap.add_argument("--variants", default="0,1,2")
+    ap.add_argument("--variants", default="1,2,3")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
     a = ap.parse_args()
+    if a.only:
+        GEMMS[:] = [g for g in GEMMS if a.only in g[0]]
+        CONVS[:] = [c for c in CONVS if a.only in c[0]]
     vs = [int(v) for v in a.variants.split(",")]
     if a.what in ("gemm", "all"):
         bench_gemm(vs, a.rounds)
