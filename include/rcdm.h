@@ -65,10 +65,13 @@ typedef struct {
 } rcdm_gemm_desc;
 
 size_t rcdm_gemm_workspace_bytes(const rcdm_gemm_desc* d);
-/* tuning/test knob for rcdm_gemm and rcdm_conv3x3: -1 = automatic (default; env RCDM_IGEMM=dma128|dma256|dma320
- * overrides), 1..3 = 128x128 / 256x256 / 256x320 (pixels x channels) tiles (3 falls back to 2 for GEGLU).
+/* tuning/test knob for rcdm_gemm and rcdm_conv3x3: -1 = automatic (default; env RCDM_IGEMM=dma128|dma256
+ * overrides), 1 = 128x128, 2 = 256x256 (pixels x channels) tiles.
  * Changes the workspace size a shape needs: query rcdm_*_workspace_bytes after setting it. */
 int rcdm_set_igemm_variant(int32_t variant);
+/* debug: when non-NULL, every igemm block writes 4 int64 {start, end (s_memtime ticks), ticks spent in epilogues,
+ * k-steps done} at trace[(blockIdx.y*gridDim.x + blockIdx.x)*4]; NULL (default) disables it. */
+int rcdm_debug_set_igemm_trace(void* device_buffer);
 int rcdm_gemm(const rcdm_gemm_desc* d, const void* A, const void* W, const float* bias,
               const float* rowvec, const void* residual, void* out, void* workspace,
               size_t workspace_bytes, void* stream);

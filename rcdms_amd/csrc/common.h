@@ -44,7 +44,13 @@ __device__ __forceinline__ float erf_as(float x) {
   return copysignf(r, x);
 }
 // exact-form (erf) GELU, as diffusers GEGLU.gelu -> F.gelu(approximate="none")
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_f(float x) {
+#ifdef RCDM_LIBM_ERF
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+#else
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f));
+#endif
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -22,7 +22,7 @@
 //     owns one pixel and 4 consecutive channels per register quad -> 16-byte staging of the fp32 tile through the
 //     ring stage that was just consumed, then a coalesced 16-byte-per-lane epilogue (bias / per-sample row vector /
 //     residual / GEGLU / scale, fp32, one rounding) while the other stage already receives the next tile.
-//   tiles <BM, BN, WM x WN waves>: 128x128 (2x2, two blocks/CU), 256x256 (2x4), 256x320 (4x2).
+//   tiles <BM, BN, WM x WN waves>: 128x128 (2x2, two blocks per CU) and 256x256 (2x4, one block per CU).
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
@@ -45,6 +45,7 @@ struct IgemmArgs {
   int epi;
   float out_scale;
   int tilesM, tilesN, kc, nk, splits, nk_per_split;
+  long long* trace;  // debug: per-block s_memtime stamps (rcdm_debug_set_igemm_trace), normally null
 };
 
 // GEGLU packing (rcdm_pack_geglu_rows): packed rows/columns come in groups of 64 = 32 "hidden" + their 32 "gate";
@@ -52,25 +53,38 @@ struct IgemmArgs {
 __device__ __forceinline__ int geglu_out_col(int n) { return (n >> 6) * 32 + (n & 31); }
 
 // v: 8 accumulated values of row m at packed columns n..n+7 (GEGLU: g = the matching gate columns n+32..).
+// n is a multiple of 8, so every per-column vector (bias, row vector) is fetched as two aligned float4.
+__device__ __forceinline__ void load8(const float* src, float (&d)[8]) {
+  const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+  d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; d[3] = a[3];
+  d[4] = b[0]; d[5] = b[1]; d[6] = b[2]; d[7] = b[3];
+}
+
 __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n, float (&v)[8], float (&g)[8]) {
   int oc = n;
   if (p.epi & RCDM_EPI_GEGLU) {
+    if (p.epi & RCDM_EPI_BIAS) {
+      float bh[8], bg[8];
+      load8(p.bias + n, bh);
+      load8(p.bias + n + 32, bg);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float hv = v[e], gv = g[e];
-      if (p.epi & RCDM_EPI_BIAS) {
-        hv += p.bias[n + e];
-        gv += p.bias[n + 32 + e];
+      for (int e = 0; e < 8; ++e) {
+        v[e] += bh[e];
+        g[e] += bg[e];
       }
-      v[e] = hv * gelu_f(gv);
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= gelu_f(g[e]);
     oc = geglu_out_col(n);
   } else if (p.epi & RCDM_EPI_BIAS) {
+    float bb[8];
+    load8(p.bias + n, bb);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+    for (int e = 0; e < 8; ++e) v[e] += bb[e];
   }
   if (p.epi & RCDM_EPI_ROWVEC) {
-    const float* rv = p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + oc;
+    float rv[8];
+    load8(p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + oc, rv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += rv[e];
   }
@@ -208,6 +222,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  long long ts0 = 0, ts_loop = 0, ts_epi = 0;
+  if (p.trace) ts0 = __builtin_amdgcn_s_memtime();
   int cm0, cn0;               // tile being computed
   tile_of(0, cm0, cn0);
   setup_loader(cm0, cn0);
@@ -247,6 +263,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
     if (++c_ks < nkl) continue;
+    long long te0 = 0;
+    if (p.trace) te0 = __builtin_amdgcn_s_memtime();
 
     // ---- tile done: epilogue.  The stage just consumed (g&1) is idle until step g+2 is issued after the next
     // barrier, so it serves as the fp32 staging tile ([RP rows][BN] floats, 16-B chunks XOR-swizzled by row) for a
@@ -258,8 +276,45 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
       constexpr int NPASS = BM_ / RP;
       constexpr int NT = NW * 64;
       float* sC = (float*)(smem + (g & 1) * STAGE_BYTES);
+      // plain (non split-K, non GEGLU) tiles: every global read of the WHOLE tile's epilogue (residual rows,
+      // row-vector slices, bias) is issued here, before the first staging barrier, so the round trips overlap the
+      // LDS staging instead of serialising one dependent load per output chunk
+      constexpr int P_TPR = BN_ / 8, P_RPI = NT / P_TPR, P_ITEMS = RP / P_RPI;
+      static_assert(NT % P_TPR == 0 && RP % P_RPI == 0, "epilogue sweep must tile the pass exactly");
+      const bool plain = p.splits == 1 && !geglu;
+      const int pc8 = t % P_TPR, pr0 = t / P_TPR;
+      const int pn = cn0 + pc8 * 8;
+      const bool pn_ok = pn < p.N;
+      constexpr bool WHOLE = NPASS * P_ITEMS <= 8;  // register budget: 256-row tiles prefetch one pass at a time
+      Pack16 resv[WHOLE ? NPASS : 1][P_ITEMS];
+      float bb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bb[e] = 0.f;
+      if (plain) {
+        if ((p.epi & RCDM_EPI_BIAS) && pn_ok) load8(p.bias + pn, bb);
+        if (WHOLE) {
+#pragma unroll
+          for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int it = 0; it < P_ITEMS; ++it) {
+              const int m = cm0 + ps * RP + pr0 + it * P_RPI;
+              resv[WHOLE ? ps : 0][it].u = make_uint4(0, 0, 0, 0);
+              if ((p.epi & RCDM_EPI_RESIDUAL) && m < p.M && pn_ok)
+                resv[WHOLE ? ps : 0][it].u = *(const uint4*)(p.res + (size_t)m * p.ldr + pn);
+            }
+        }
+      }
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
+        if (plain && !WHOLE) {
+#pragma unroll
+          for (int it = 0; it < P_ITEMS; ++it) {
+            const int m = cm0 + ps * RP + pr0 + it * P_RPI;
+            resv[0][it].u = make_uint4(0, 0, 0, 0);
+            if ((p.epi & RCDM_EPI_RESIDUAL) && m < p.M && pn_ok)
+              resv[0][it].u = *(const uint4*)(p.res + (size_t)m * p.ldr + pn);
+          }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // operand reads (ps = 0) / previous pass's staged reads are complete
 #pragma unroll
@@ -281,10 +336,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
         __builtin_amdgcn_s_barrier();
         const int mbase = cm0 + ps * RP;
         if (p.splits > 1) {
+          constexpr int TPR = BN_ / 8, RPI = NT / TPR, ITEMS = RP / RPI;  // threads per row, rows per sweep
+          static_assert(NT % TPR == 0 && RP % RPI == 0, "epilogue sweep must tile the pass exactly");
           float* dst = p.partial + (size_t)blockIdx.y * p.M * p.N;
-          for (int idx = t; idx < RP * (BN_ / 8); idx += NT) {
-            const int row = idx / (BN_ / 8), c8 = idx - row * (BN_ / 8);
-            const int m = mbase + row, n = cn0 + c8 * 8;
+          const int c8 = t % TPR, r0 = t / TPR;
+          const int n = cn0 + c8 * 8;
+#pragma unroll
+          for (int it = 0; it < ITEMS; ++it) {
+            const int row = r0 + it * RPI;
+            const int m = mbase + row;
             if (m < p.M && n < p.N) {
               const f32x4 v0 = *(const f32x4*)(sC + row * BN_ + (((2 * c8) ^ (row & 7)) << 2));
               const f32x4 v1 = *(const f32x4*)(sC + row * BN_ + (((2 * c8 + 1) ^ (row & 7)) << 2));
@@ -293,30 +353,55 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
             }
           }
         } else if (geglu) {
-          for (int idx = t; idx < RP * (BN_ / 16); idx += NT) {
-            const int row = idx / (BN_ / 16), oc8 = idx - row * (BN_ / 16);   // 8 outputs per item
-            const int hch = (oc8 >> 2) * 16 + (oc8 & 3) * 2;                   // 16-B chunk of the hidden columns
+          constexpr int TPR = BN_ / 16, RPI = NT / TPR, ITEMS = RP / RPI;  // 8 outputs per item
+          static_assert(NT % TPR == 0 && RP % RPI == 0, "epilogue sweep must tile the pass exactly");
+          const int oc8 = t % TPR, r0 = t / TPR;
+          const int hch = (oc8 >> 2) * 16 + (oc8 & 3) * 2;  // 16-B chunk of the hidden columns inside the tile
+          const int n = cn0 + hch * 4;
+          float bh[8], bg[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bh[e] = bg[e] = 0.f;
+          if (p.epi & RCDM_EPI_BIAS) {
+            load8(p.bias + n, bh);
+            load8(p.bias + n + 32, bg);
+          }
+          const int oc = geglu_out_col(n);
+#pragma unroll
+          for (int it = 0; it < ITEMS; ++it) {
+            const int row = r0 + it * RPI;
             const int m = mbase + row;
             if (m < p.M) {
               const f32x4 h0 = *(const f32x4*)(sC + row * BN_ + ((hch ^ (row & 7)) << 2));
               const f32x4 h1 = *(const f32x4*)(sC + row * BN_ + (((hch + 1) ^ (row & 7)) << 2));
               const f32x4 g0 = *(const f32x4*)(sC + row * BN_ + (((hch + 8) ^ (row & 7)) << 2));
               const f32x4 g1 = *(const f32x4*)(sC + row * BN_ + (((hch + 9) ^ (row & 7)) << 2));
-              float v[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-              float gt[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-              epilogue_store(p, m, cn0 + hch * 4, v, gt);
+              const float hv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+              const float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+              Pack16 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o.e[e] = (f16)((hv[e] + bh[e]) * gelu_f(gv[e] + bg[e]) * p.out_scale);
+              *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
             }
           }
         } else {
-          for (int idx = t; idx < RP * (BN_ / 8); idx += NT) {
-            const int row = idx / (BN_ / 8), c8 = idx - row * (BN_ / 8);
-            const int m = mbase + row, n = cn0 + c8 * 8;
-            if (m < p.M && n < p.N) {
-              const f32x4 v0 = *(const f32x4*)(sC + row * BN_ + (((2 * c8) ^ (row & 7)) << 2));
-              const f32x4 v1 = *(const f32x4*)(sC + row * BN_ + (((2 * c8 + 1) ^ (row & 7)) << 2));
+#pragma unroll
+          for (int it = 0; it < P_ITEMS; ++it) {
+            const int row = pr0 + it * P_RPI;
+            const int m = mbase + row;
+            if (m < p.M && pn_ok) {
+              const f32x4 v0 = *(const f32x4*)(sC + row * BN_ + (((2 * pc8) ^ (row & 7)) << 2));
+              const f32x4 v1 = *(const f32x4*)(sC + row * BN_ + (((2 * pc8 + 1) ^ (row & 7)) << 2));
               float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-              float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-              epilogue_store(p, m, n, v, gt);
+              if (p.epi & RCDM_EPI_ROWVEC) {  // per-sample vector: L1/L2 resident (a few KB), read in place
+                float rv[8];
+                load8(p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + pn, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+              }
+              Pack16 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + bb[e] + (float)resv[WHOLE ? ps : 0][it].e[e]) * p.out_scale);
+              *(uint4*)(p.out + (size_t)m * p.ldc + pn) = o.u;
             }
           }
         }
@@ -330,7 +415,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     ++c_tile;
     if (c_tile < my_tiles) tile_of(c_tile, cm0, cn0);
+    if (p.trace) ts_epi += __builtin_amdgcn_s_memtime() - te0;
   }
+  if (p.trace && t == 0) {
+    long long* o = p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    o[0] = ts0;
+    o[1] = __builtin_amdgcn_s_memtime();
+    o[2] = ts_epi;
+    o[3] = my_tiles * nkl;
+  }
+  (void)ts_loop;
 }
 
 // split-K second pass: fixed-order sum of the fp32 slabs + the epilogue (8 output columns per thread).
@@ -367,11 +461,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
   }
 }
 
-// variant: 1 = 128x128, 2 = 256x256, 3 = 256x320  (-1 = heuristic)
+// variant: 1 = 128x128, 2 = 256x256  (-1 = heuristic)
 int g_force_variant = -1;
 struct TileCfg { int bm, bn, blocks_per_cu; };
-const TileCfg kTiles[4] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}, {256, 320, 1}};
+const TileCfg kTiles[3] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}};
 int g_num_cus = 0;
+long long* g_trace = nullptr;
 
 int num_cus() {
   if (g_num_cus <= 0) {
@@ -391,12 +486,8 @@ int pick_variant(const IgemmArgs& a) {
     g_force_variant = 99;
     if (e && !strcmp(e, "dma128")) g_force_variant = 1;
     if (e && !strcmp(e, "dma256")) g_force_variant = 2;
-    if (e && !strcmp(e, "dma320")) g_force_variant = 3;
   }
-  if (g_force_variant != 99) {
-    if (g_force_variant == 3 && (a.epi & RCDM_EPI_GEGLU)) return 2;  // 160-column wave tiles cannot pair 32|32 groups
-    return g_force_variant == 0 ? 1 : g_force_variant;
-  }
+  if (g_force_variant != 99) return g_force_variant == 0 ? 1 : g_force_variant;
   // measured (tools/kbench.py, MI355X): 128x128 (two blocks per CU) wins everywhere except the tiny-M, long-K
   // convs of the 8x8 level, where 256x256 + split-K reads each weight tile half as often.
   if (a.Ktot > a.Cin && a.M <= 1024 && a.N % 256 == 0) return 2;
@@ -455,12 +546,10 @@ template <int TAPS>
 int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   constexpr int LDS_128 = 2 * (128 + 128) * 128;  // 64 KB  (two blocks per CU)
   constexpr int LDS_256 = 2 * (256 + 256) * 128;  // 128 KB
-  constexpr int LDS_320 = 2 * (256 + 320) * 128;  // 144 KB
   static bool attr_set = false;
   if (!attr_set) {
     set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2>, LDS_128);
     set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4>, LDS_256);
-    set_lds(igemm_dma_kernel<TAPS, 256, 320, 4, 2>, LDS_320);
     attr_set = true;
   }
   if (a.splits > 1) {
@@ -470,15 +559,22 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   } else {
     a.partial = nullptr;
   }
+  a.trace = g_trace;
   const int ntiles = a.tilesM * a.tilesN;
   int gx = num_cus() * kTiles[variant].blocks_per_cu;
   if (a.splits > 1) gx = (gx + a.splits - 1) / a.splits;
   gx = (gx + 7) / 8 * 8;  // keep the b%8 -> XCD pattern aligned across the persistent stride
+  static int persist_mode = -1;  // RCDM_PERSIST: 0 = one tile per block, 1 = always persistent, 2 = auto
+  if (persist_mode < 0) {
+    const char* e = getenv("RCDM_PERSIST");
+    persist_mode = e ? atoi(e) : 2;
+  }
+  // a persistent block must drain its epilogue stores (vmcnt counts stores too) before it can trust the next
+  // tile's DMA: with many short tiles per block (GEGLU: 12+ tiles of 5 k-steps) that stall outweighs the prefetch
+  if (persist_mode == 0 || (persist_mode == 2 && (a.epi & RCDM_EPI_GEGLU))) gx = ntiles;
   if (gx > ntiles) gx = ntiles;
   dim3 grid(gx, a.splits);
-  if (variant == 3)
-    hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 256, 320, 4, 2>), grid, dim3(512), LDS_320, stream, a);
-  else if (variant == 2)
+  if (variant == 2)
     hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 256, 256, 2, 4>), grid, dim3(512), LDS_256, stream, a);
   else
     hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 128, 128, 2, 2>), grid, dim3(256), LDS_128, stream, a);
@@ -521,8 +617,13 @@ int from_conv(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
 extern "C" {
 
 int rcdm_set_igemm_variant(int32_t v) {
-  if (v < -1 || v > 3) return RCDM_EINVAL;
+  if (v < -1 || v > 2) return RCDM_EINVAL;
   g_force_variant = v < 0 ? 99 : v;
+  return RCDM_OK;
+}
+
+int rcdm_debug_set_igemm_trace(void* device_buffer) {
+  g_trace = (long long*)device_buffer;
   return RCDM_OK;
 }
 

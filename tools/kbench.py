@@ -145,7 +145,7 @@ def bench_norm(rounds):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
-    ap.add_argument("--variants", default="1,2,3")
+    ap.add_argument("--variants", default="1,2")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     a = ap.parse_args()
