@@ -162,12 +162,22 @@ def main():
     launches = a.steps * T
     avg_launch_ms = gpu_ms / launches
     tf_call = ALGO_TFLOP_PER_CALL.get(a.latent)
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/collect_profiles.sh); bench.py cannot run
+    # the profiler on itself, so it reports the committed measurement for this exact workload, else null.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath) and S == 1 and a.latent == 64 and a.guidance > 1:
+        try:
+            with open(tpath) as f:
+                traffic = float(json.load(f)["hbm_bytes_per_unet_step"])
+        except Exception:
+            traffic = None
     roof = None
     if tf_call is not None:
         achieved = tf_call * S / (avg_launch_ms * 1e-3)
         roof = {"bound": "mfma", "kernel": "denoise-step graph (UNet b=%d + CFG + DDIM)" % (2 * S if a.guidance > 1 else S),
                 "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches}
 
     out = {

@@ -1,0 +1,62 @@
+"""CPU, world_size 2, gloo: the multi-process helpers of rcdms_amd/dist.py (story sharding, bucketed weight broadcast,
+context broadcast, result gather).  The denoising loop itself has no collective, so this is the whole N>1 surface."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from rcdms_amd.dist import broadcast_context, broadcast_module, gather_stories, split_stories
+
+
+def test_split_stories_matches_reference_split_list():
+    assert split_stories(10, 4) == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
+    assert split_stories(3, 4) == [[0], [1], [2], []]
+    assert sum(len(s) for s in split_stories(1001, 8)) == 1001
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                       # different weights per rank before the broadcast
+        m = nn.Sequential(nn.Linear(37, 53), nn.LayerNorm(53), nn.Linear(53, 11))
+        m.register_buffer("pe", torch.randn(1, 5, 8))
+        broadcast_module(m, src=0, bucket_bytes=4096)        # force several buckets
+        digest = torch.cat([t.reshape(-1).double() for t in m.state_dict().values()]).sum().item()
+        ctx = torch.full((4, 3), float(rank))
+        broadcast_context(ctx, src=0)
+        shard = split_stories(5, world)[rank]
+        lat = torch.stack([torch.full((4, 5, 2, 2), float(i)) for i in shard]) if shard else torch.zeros(0, 4, 5, 2, 2)
+        # gather needs equal shapes: pad shards to the longest one (what a driver would do for ragged shards)
+        longest = max(len(s) for s in split_stories(5, world))
+        pad = torch.full((longest - lat.shape[0], 4, 5, 2, 2), -1.0)
+        out = gather_stories(torch.cat([lat, pad]), dst=0)
+        q.put((rank, digest, ctx.sum().item(), None if out is None else out[:, 0, 0, 0, 0].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, d0, c0, g0), (r1, d1, c1, g1) = res
+    assert d0 == d1, "weights differ after broadcast"
+    assert c0 == 0.0 and c1 == 0.0
+    assert g0 == [0.0, 1.0, 2.0, 3.0, 4.0, -1.0] and g1 is None
