@@ -12,7 +12,7 @@ LIB = os.path.join(LIBDIR, "librcdm_hip.so")
 SOURCES = ["igemm.hip", "norm.hip", "attn.hip", "misc.hip", "runtime.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-         "-Wno-unused-result"]
+         "-Wno-unused-result"] + os.environ.get("RCDM_CXXFLAGS", "").split()
 
 
 def _stamp():
