@@ -488,22 +488,22 @@ int pick_variant(const IgemmArgs& a) {
     if (e && !strcmp(e, "dma256")) g_force_variant = 2;
   }
   if (g_force_variant != 99) return g_force_variant == 0 ? 1 : g_force_variant;
-  // measured (tools/kbench.py, MI355X): 128x128 (two blocks per CU) wins everywhere except the tiny-M, long-K
-  // convs of the 8x8 level, where 256x256 + split-K reads each weight tile half as often.
-  if (a.Ktot > a.Cin && a.M <= 1024 && a.N % 256 == 0) return 2;
+  // measured (tools/kbench.py, tools/splitk_test.py, MI355X): 128x128 tiles with two blocks per CU win on every
+  // shape of this UNet once split-K is planned per plan_splits(); 256x256 stays available as variant 2.
   return 1;
 }
 
+// Split-K only pays when (a) all tiles x splits still run as ONE round of resident blocks (a second, partly filled
+// round costs more than the idle CUs it fills) and (b) every slice keeps >= ~20 k-steps, because the fp32 slabs and
+// the reduce pass are not free (measured with tools/splitk_test.py: e.g. M=2560 N=1280 K=1280 is 21 us unsplit and
+// 33 us split 3 ways; the 8x8-level convs (50 tiles, 180 k-steps) drop from 150 us to 40 us split 8 ways).
 int plan_splits(int tiles, int slots, int nk, int requested) {
   if (requested == 1) return 1;
   if (requested > 1) return requested < nk ? requested : nk;
-  int s = 1;
-  if (tiles * 4 < slots * 3 && nk >= 8) {  // under 3/4 of one wave of blocks
-    s = (slots + tiles - 1) / tiles;
-    if (s > nk / 4) s = nk / 4;
-    if (s > 16) s = 16;
-    if (s < 1) s = 1;
-  }
+  int s = slots / (tiles > 0 ? tiles : 1);
+  if (s > nk / 20) s = nk / 20;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
   return s;
 }
 
