@@ -20,12 +20,22 @@ __global__ void timestep_embed_kernel(const float* __restrict__ t, int rows, int
   out[(size_t)r * dim + half + i] = sinf(a);
 }
 
-// one wave per output column n; rows <= 8 kept as static-indexed accumulators.
+// one wave per output column n; rows <= 8 kept as static-indexed accumulators.  The (optionally SiLU'd) input rows
+// are staged once per block in LDS (rows*K floats) and read back as float4, the weight row streams as 16-byte loads.
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int rows, int K,
                                                            const f16* __restrict__ W, const float* __restrict__ bias,
                                                            int N, int silu_in, int silu_out, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sx = (float*)smem;  // [rows][K]
+  for (int i = threadIdx.x; i < rows * K; i += 256) {
+    float v = x[i];
+    if (silu_in) v = silu_f(v);
+    sx[i] = v;
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int j = 0; j < 4; ++j) {  // 16 output columns per block: the staged input is reused 16 times
+  const int n = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + j;
   if (n >= N) return;
   float acc[8];
 #pragma unroll
@@ -33,14 +43,17 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
   for (int k = lane * 8; k < K; k += 512) {
     Pack16 w;
     w.u = *(const uint4*)(W + (size_t)n * K + k);
+    float wf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wf[e] = (float)w.e[e];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       if (r < rows) {
+        const f32x4 x0 = *(const f32x4*)(sx + r * K + k), x1 = *(const f32x4*)(sx + r * K + k + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float xv = x[(size_t)r * K + k + e];
-          if (silu_in) xv = silu_f(xv);
-          acc[r] = fmaf(xv, (float)w.e[e], acc[r]);
+        for (int e = 0; e < 4; ++e) {
+          acc[r] = fmaf(x0[e], wf[e], acc[r]);
+          acc[r] = fmaf(x1[e], wf[4 + e], acc[r]);
         }
       }
     }
@@ -55,6 +68,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
         out[(size_t)r * N + n] = v;
       }
     }
+  }
   }
 }
 
@@ -181,8 +195,9 @@ int rcdm_timestep_embed(const float* t, int32_t rows, int32_t dim, float* out, v
 int rcdm_small_linear(const float* x, int32_t rows, int32_t K, const void* W, const float* bias, int32_t N,
                       int32_t silu_in, int32_t silu_out, float* out, void* stream) {
   if (!x || !W || !out || rows <= 0 || K <= 0 || N <= 0) return RCDM_EINVAL;
-  if (rows > 8 || (K & 7)) return RCDM_ESHAPE;
-  hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, K,
+  if (rows > 8 || (K & 7) || (size_t)rows * K * sizeof(float) > 64 * 1024) return RCDM_ESHAPE;
+  hipLaunchKernelGGL(small_linear_kernel, dim3((N + 15) / 16), dim3(256), (size_t)rows * K * sizeof(float),
+                     (hipStream_t)stream, x, rows, K,
                      (const f16*)W, bias, N, silu_in, silu_out, out);
   return rcdm_check_launch();
 }

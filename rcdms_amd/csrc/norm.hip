@@ -114,14 +114,17 @@ __global__ void gn_apply_kernel(const GnArgs p) {
   const int ch = t % p.CH, rl = t / p.CH;
   const int s = blockIdx.y;
   float sc[8], sh[8];
+  {
+    const f32x4 g0 = *(const f32x4*)(p.gamma + ch * 8), g1 = *(const f32x4*)(p.gamma + ch * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(p.beta + ch * 8), b1 = *(const f32x4*)(p.beta + ch * 8 + 4);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = ch * 8 + e;
-    const int g = c / p.cg;
-    const float mean = p.stat[(s * p.G + g) * 2], rstd = p.stat[(s * p.G + g) * 2 + 1];
-    const float ga = p.gamma[c], be = p.beta[c];
-    sc[e] = rstd * ga;
-    sh[e] = be - mean * rstd * ga;
+    for (int e = 0; e < 8; ++e) {
+      const int g = (ch * 8 + e) / p.cg;
+      const float mean = p.stat[(s * p.G + g) * 2], rstd = p.stat[(s * p.G + g) * 2 + 1];
+      const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
+      sc[e] = rstd * ga;
+      sh[e] = be - mean * rstd * ga;
+    }
   }
   const f16* xb = p.x + (size_t)s * p.P * p.ldx + ch * 8;
   f16* yb = p.y + (size_t)s * p.P * p.ldy + ch * 8;
@@ -184,10 +187,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
+    // two aligned float4 per 8-channel chunk (the scalar form was 16 dword loads per chunk per lane)
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, b0 = g0, b1 = g0;
+    if (c < nchunks) {
+      g0 = *(const f32x4*)(gamma + c * 8);
+      g1 = *(const f32x4*)(gamma + c * 8 + 4);
+      b0 = *(const f32x4*)(beta + c * 8);
+      b1 = *(const f32x4*)(beta + c * 8 + 4);
+    }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      gm[i][e] = c < nchunks ? gamma[c * 8 + e] : 0.f;
-      bt[i][e] = c < nchunks ? beta[c * 8 + e] : 0.f;
+    for (int e = 0; e < 4; ++e) {
+      gm[i][e] = g0[e];
+      gm[i][4 + e] = g1[e];
+      bt[i][e] = b0[e];
+      bt[i][4 + e] = b1[e];
     }
   }
 #pragma unroll
@@ -223,10 +236,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
         const int c = lane + 64 * i;
         if (c < nchunks) {
           Pack16 o;
+          f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+          if (pe_row) {
+            p0 = *(const f32x4*)(pe_row + c * 8);
+            p1 = *(const f32x4*)(pe_row + c * 8 + 4);
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float f = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
-            if (pe_row) f += pe_row[c * 8 + e];
+            const float f = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e] + (e < 4 ? p0[e & 3] : p1[e & 3]);
             o.e[e] = (f16)f;
           }
           *(uint4*)(y + (size_t)row * ldy + c * 8) = o.u;
