@@ -63,8 +63,8 @@ def build_model(device):
 
 def cpu_baseline(model, latent, ctx_len, ddim_steps, budget_s=25.0):
     """Oracle (CPU fp32 restatement of the reference, kind "port") on this box's host cores, BOUNDED: one UNet call of
-    the 50 at 32x32 latents first (2.556 TFLOP); if that took under budget_s/6 the real 64x64 call is timed too,
-    otherwise the 64x64 time is extrapolated by the algorithmic-FLOP ratio 11.044 / 2.556 (said in `sample`).
+    the 50 at 32x32 latents first (2.556 TFLOP); if the FLOP-scaled estimate of the real 64x64 call fits 1.8 x budget_s it is
+    timed directly, otherwise its time is extrapolated by the algorithmic-FLOP ratio 11.044 / 2.556 (said in `sample`).
     torch CPU scales badly past a few dozen threads, so at most 64 are used; `cores` reports the threads used."""
     from oracle import unet_oracle as O
     from rcdms_amd import synth
@@ -81,7 +81,7 @@ def cpu_baseline(model, latent, ctx_len, ddim_steps, budget_s=25.0):
         return time.time() - t0
 
     t32 = one_call(32)
-    if latent == 64 and t32 < budget_s / 6:
+    if latent == 64 and t32 * ALGO_TFLOP_PER_CALL[64] / ALGO_TFLOP_PER_CALL[32] < 1.8 * budget_s:
         t_call = one_call(64)
         how = f"1 UNet call of the {ddim_steps} per story at 64x64 latents timed directly ({t_call:.1f} s; 32x32 probe {t32:.1f} s)"
     elif latent == 64:

@@ -6,18 +6,18 @@
 // plus the head split/merge copies :93-105; and VersatileAttention.forward
 // src/models/motion_module.py:294-354 (the "(b f) d c <-> (b d) f c" regroup + 5x5 attention).
 //
-// Spatial kernel: a block = 4 waves x 32 queries; K/V tiles of 64 keys staged in LDS.
+// Spatial kernel: a block = 4 waves x 32 queries; K/V tiles of 64 keys staged row-major in ping-pong LDS images.
 // Scores are computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_f16, keys = rows, queries = cols),
 // so a lane owns ONE query column: row max / sum / rescale are lane-local (+1 exchange with lane^32),
-// and the exponentiated registers feed the second MFMA, O^T = V^T P^T, directly as its B operand:
-// the key order inside each 16-key step only has to agree between P (registers) and V^T (LDS image),
-// so V is transposed into LDS with the matching key permutation and no cross-lane shuffle is needed.
+// and the exponentiated registers feed the second MFMA, O^T = V^T P^T, directly as its B operand.
+// Its A operand (head-dim rows x keys) is read from the row-major V image with gfx950's LDS transpose read
+// (ds_read_b64_tr_b16), in the key order the S^T accumulator registers hold P, so V needs no transposing
+// scatter on the way in and no cross-lane shuffle on the way out.
 #include "common.h"
 
 namespace {
 
 constexpr int KT = 64;        // keys per tile
-constexpr int VP = KT + 8;    // halfs per V^T row (144 B)
 
 struct AttnArgs {
   const f16* Q;
@@ -29,10 +29,15 @@ struct AttnArgs {
   float c;  // scale * log2(e)
 };
 
-// position of key k (0..63) inside a V^T row: within each 16-key step the lane group `hi` must find
-// its 8 keys contiguous, in the order the S^T accumulator registers hold them.
-__device__ __forceinline__ int vt_pos(int k) {
-  return (k & ~15) + 8 * ((k >> 2) & 1) + (k & 3) + 4 * ((k >> 3) & 1);
+// V row stride in LDS (halfs) for 32*DF padded columns: the smallest >= 64*DF bytes whose dword stride is 16 or 48
+// (mod 64), so the four key rows one ds_read_b64_tr_b16 lane group touches fall in four different 16-bank slots.
+__host__ __device__ constexpr int v_row_halfs(int DF) { return DF == 1 ? 32 : DF <= 3 ? 96 : 160; }
+
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+// gfx950 LDS transpose read: every 16-lane group reads a [4 keys][16 columns] f16 block (lane i supplies the address
+// of row i/4, columns 4(i%4)..+3) and lane i receives column i of that block, i.e. 4 keys of one head-dim column.
+__device__ __forceinline__ s16x4 lds_read_tr16(const f16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
 __device__ __forceinline__ float max3f(float a, float b, float c) {
@@ -45,43 +50,54 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // ~4 VALU ops per score: raw v_exp_f32, v_max3 row max, packed RTZ f16 conversion, the row SUM taken from a
 // ones-row appended to V^T (it falls out of the PV MFMA, consistently with the rounded P), the O rescale skipped
 // while the running max does not move, and all K/V staging index math hoisted out of the key-tile loop.
-template <int DS>  // d padded to 16*DS for QK^T and to 32*DF for PV
+template <int DS, int QF, bool PIPE>  // d padded to 16*DS for QK^T and to 32*DF for PV; a wave owns QF fragments of 32 queries
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
   constexpr int DF = (DS + 1) / 2;
   constexpr int KP = 16 * DS + 8;  // halfs per K row
   constexpr int NSLOT = (KT * 2 * DS + 255) / 256;  // 16-B chunks a thread stages per tile (K and V each)
+  constexpr int BQ = 128 * QF;                      // queries per block
+  constexpr int VR = v_row_halfs(DF);               // halfs per V row
+  constexpr int SK = KT * KP, SV = KT * VR;         // halfs per K / V image; two of each (ping-pong)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  f16* sK = (f16*)smem;           // [KT][KP]
-  f16* sVt = sK + KT * KP;        // [32*DF][VP]
+  f16* sK = (f16*)smem;           // [2][KT][KP]
+  f16* sV = sK + 2 * SK;          // [2][KT][VR]  row-major, read transposed
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q = blockIdx.x * 128 + wave * 32 + lr;
-  const bool q_ok = q < p.Lq;
-  const bool ones_row = p.d < 32 * DF;  // a spare V^T row exists: row d := 1 gives sum_k P[k][q] for free
+  const int q0 = blockIdx.x * BQ + wave * 32 * QF + lr;  // fragment j holds query q0 + 32 j
+  // a spare V column exists: column d := 1 gives sum_k P[k][q] for free.  Always true for odd DS (d <= 16 DS < 32 DF).
+  const bool ones_row = (DS & 1) ? true : p.d < 32 * DF;
 
-  // zero both LDS images once: pad columns of K and pad rows of V^T stay zero afterwards
-  for (int i = t; i < (KT * KP + 32 * DF * VP) / 8; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+  // zero the LDS images once: the pad columns of K and V stay zero afterwards
+  for (int i = t; i < (2 * SK + 2 * SV) / 8; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
-  if (ones_row && t < KT) sVt[p.d * VP + t] = (f16)1.0f;
+  if (ones_row && t < 2 * KT) sV[(t >> 6) * SV + (t & 63) * VR + p.d] = (f16)1.0f;
 
-  f16x8 qf[DS];
+  f16x8 qf[QF][DS];
 #pragma unroll
-  for (int s = 0; s < DS; ++s) {
-    const int dc = s * 16 + hi * 8;
-    Pack16 v;
-    v.u = make_uint4(0, 0, 0, 0);
-    if (q_ok && dc < p.d) v.u = *(const uint4*)(p.Q + ((size_t)b * p.Lq + q) * p.ldq + h * p.d + dc);
-    qf[s] = v.h;
+  for (int j = 0; j < QF; ++j)
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+      const int dc = s * 16 + hi * 8;
+      Pack16 v;
+      v.u = make_uint4(0, 0, 0, 0);
+      if (q0 + 32 * j < p.Lq && dc < p.d)
+        v.u = *(const uint4*)(p.Q + ((size_t)b * p.Lq + q0 + 32 * j) * p.ldq + h * p.d + dc);
+      qf[j][s] = v.h;
+    }
+
+  f32x16 oacc[QF][DF];
+  float m_run[QF], l_run[QF];
+#pragma unroll
+  for (int j = 0; j < QF; ++j) {
+    m_run[j] = -INFINITY;
+    l_run[j] = 0.f;
+#pragma unroll
+    for (int f = 0; f < DF; ++f)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[j][f][e] = 0.f;
   }
-
-  f32x16 oacc[DF];
-#pragma unroll
-  for (int f = 0; f < DF; ++f)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[f][e] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
 
   const f16* Kb = p.K + (size_t)b * p.Lk * p.ldk + h * p.d;
   const f16* Vb = p.V + (size_t)b * p.Lk * p.ldv + h * p.d;
@@ -89,136 +105,207 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
   const int nchunks = KT * p.dch;
 
   // ---- staging slots: loop-invariant (key, chunk) of the 16-B pieces this thread moves every tile ----------
-  int k_key[NSLOT], k_lds[NSLOT], v_key[NSLOT], v_lds[NSLOT];
-  size_t k_src[NSLOT], v_src[NSLOT];
+  // Loads are raw buffer loads: a slot this thread does not own, and keys past Lk (last tile and the tiles the
+  // pipeline over-fetches past the end), fall outside num_records and read as zero without branches.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)Kb, 0, (int)(((size_t)(p.Lk - 1) * p.ldk + p.dch * 8) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)Vb, 0, (int)(((size_t)(p.Lk - 1) * p.ldv + p.dch * 8) * 2), 0x00020000);
+  int k_lds[NSLOT], v_lds[NSLOT];
+  unsigned k_off[NSLOT], v_off[NSLOT];  // byte offsets of the NEXT K / V tile to fetch
   bool s_ok[NSLOT];
 #pragma unroll
   for (int sl = 0; sl < NSLOT; ++sl) {
     const int idx = t + 256 * sl;
     s_ok[sl] = idx < nchunks;
-    const int key = idx / p.dch, c = idx - key * p.dch;  // K: chunk fastest (contiguous in HBM and LDS)
-    k_key[sl] = key;
+    const int key = idx / p.dch, c = idx - key * p.dch;  // chunk fastest: contiguous in HBM and in LDS
     k_lds[sl] = key * KP + c * 8;
-    k_src[sl] = (size_t)key * p.ldk + c * 8;
-    const int vkey = idx & (KT - 1), vc = idx >> 6;      // V: key fastest (one V^T row per transposing write)
-    v_key[sl] = vkey;
-    v_lds[sl] = vc * 8 * VP + vt_pos(vkey);
-    v_src[sl] = (size_t)vkey * p.ldv + vc * 8;
+    v_lds[sl] = key * VR + c * 8;
+    k_off[sl] = s_ok[sl] ? (unsigned)(key * p.ldk + c * 8) * 2u : OOB;
+    v_off[sl] = s_ok[sl] ? (unsigned)(key * p.ldv + c * 8) * 2u : OOB;
   }
+  // an OOB slot stays >= 2^31 and a live one < 2^31 while stepping: (Lk + 4 KT) * ld * 2 < 2^31 (launcher)
+  const unsigned k_step = (unsigned)(KT * p.ldk) * 2u, v_step = (unsigned)(KT * p.ldv) * 2u;
 
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int kbase = kt * KT;
-    Pack16 kreg[NSLOT], vreg[NSLOT];
+  Pack16 kreg[NSLOT], vreg[NSLOT];
+  auto fetch_k = [&]() {
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
-      kreg[sl].u = vreg[sl].u = make_uint4(0, 0, 0, 0);
-      if (s_ok[sl] && kbase + k_key[sl] < p.Lk) kreg[sl].u = *(const uint4*)(Kb + (size_t)kbase * p.ldk + k_src[sl]);
-      if (s_ok[sl] && kbase + v_key[sl] < p.Lk) vreg[sl].u = *(const uint4*)(Vb + (size_t)kbase * p.ldv + v_src[sl]);
+      kreg[sl].v = __builtin_amdgcn_raw_buffer_load_b128(rK, k_off[sl], 0, 0);
+      k_off[sl] += k_step;
     }
-    __syncthreads();  // previous tile fully consumed
+  };
+  auto fetch_v = [&]() {
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
-      if (s_ok[sl]) {
-        *(uint4*)(sK + k_lds[sl]) = kreg[sl].u;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sVt[v_lds[sl] + e * VP] = vreg[sl].e[e];
-      }
+      vreg[sl].v = __builtin_amdgcn_raw_buffer_load_b128(rV, v_off[sl], 0, 0);
+      v_off[sl] += v_step;
     }
-    __syncthreads();
-
-    // ---- S^T = K Q^T : two 32-key fragments ---------------------------------------------------
-    f32x16 sacc[2];
+  };
+  auto put_k = [&](int par) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int sl = 0; sl < NSLOT; ++sl)
+      if (s_ok[sl]) *(uint4*)(sK + par * SK + k_lds[sl]) = kreg[sl].u;
+  };
+  auto put_v = [&](int par) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sacc[f][e] = 0.f;
-#pragma unroll
-      for (int s = 0; s < DS; ++s) {
-        const f16x8 kf = *(const f16x8*)(sK + (f * 32 + lr) * KP + s * 16 + hi * 8);
-        sacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[f], 0, 0, 0);
-      }
-    }
-    // lane holds, for query lr, keys  f*32 + (r&3) + 8*(r>>2) + 4*hi
-    if (kbase + KT > p.Lk) {
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kbase + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= p.Lk) sacc[f][r] = -INFINITY;
-        }
-    }
-    float mx = max3f(sacc[0][0], sacc[0][1], sacc[0][2]);
-#pragma unroll
-    for (int r = 3; r < 15; r += 2) mx = max3f(mx, sacc[0][r], sacc[0][r + 1]);
-    mx = max3f(mx, sacc[0][15], sacc[1][0]);
-#pragma unroll
-    for (int r = 1; r < 15; r += 2) mx = max3f(mx, sacc[1][r], sacc[1][r + 1]);
-    mx = fmaxf(mx, sacc[1][15]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * p.c);  // every tile has >= 1 valid key, so m_new is finite
-    const bool moved = m_new != m_run;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
-    m_run = m_new;
-    float lsum = 0.f;
-    f16x8 pf[4];
+    for (int sl = 0; sl < NSLOT; ++sl)
+      if (s_ok[sl]) *(uint4*)(sV + par * SV + v_lds[sl]) = vreg[sl].u;
+  };
+  // transposed V fragment base: lane (hi, column half ch, i) addresses key row 4 hi + i/4, columns 16 ch + 4 (i%4)
+  const int v_rd = (4 * hi + ((lane & 15) >> 2)) * VR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  // S^T = K Q^T for one key tile: two 32-key fragments, each K fragment read once for all QF query fragments
+  auto qk = [&](int par, f32x16 (&sacc)[QF][2]) {
+    constexpr f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[f][r], p.c, -m_new));
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[f][r + 1], p.c, -m_new));
-        if (!ones_row) lsum += p0 + p1;
-        const auto pk = __builtin_amdgcn_cvt_pkrtz(p0, p1);  // v_cvt_pkrtz_f16_f32: two f16 in one VALU op
-        pf[f * 2 + (r >> 3)][r & 7] = (f16)pk[0];
-        pf[f * 2 + (r >> 3)][(r & 7) + 1] = (f16)pk[1];
+      for (int s = 0; s < DS; ++s) {
+        const f16x8 kf = *(const f16x8*)(sK + par * SK + (f * 32 + lr) * KP + s * 16 + hi * 8);
+#pragma unroll
+        for (int j = 0; j < QF; ++j)
+          sacc[j][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j][s], s == 0 ? zero : sacc[j][f], 0, 0, 0);
       }
-    if (__any(moved)) {  // wave-uniform: once the running max has settled the accumulators are left alone
-      l_run *= alpha;
-#pragma unroll
-      for (int f = 0; f < DF; ++f)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[f][e] *= alpha;
-    }
-    l_run += lsum;
+  };
 
-    // ---- O^T += V^T P^T : 4 steps of 16 keys ---------------------------------------------------
+  // ---- software pipeline ------------------------------------------------------------------------------------
+  // Iteration kt consumes S(kt) (registers, computed one iteration earlier) and V(kt) (LDS, written one iteration
+  // earlier), and meanwhile issues the QK^T MFMAs of tile kt+1, so the matrix pipe works under the softmax VALU
+  // stream of the same wave.  K tiles are staged two ahead and V tiles one ahead into ping-pong LDS images, which
+  // leaves ONE barrier per tile: everything written in iteration kt is first read in iteration kt+1, and
+  // everything read in iteration kt was written before the barrier that opens it.
+  fetch_k();  // K0
+  fetch_v();  // V0
+  put_k(0);
+  put_v(0);
+  if constexpr (PIPE) {
+    fetch_k();  // K1
+    put_k(1);
+  }
+  fetch_k();  // K2 (PIPE) or K1 -> registers
+  fetch_v();  // V1 -> registers
+  __syncthreads();
+  f32x16 s_even[QF][2], s_odd[PIPE ? QF : 1][2];
+  if constexpr (PIPE) qk(0, s_even);
+
+  auto step = [&](int kt, f32x16 (&sacc)[QF][2], f32x16 (&snext)[QF][2]) {  // !PIPE: snext aliases sacc, unused
+    const int kbase = kt * KT, par = kt & 1;
+    __syncthreads();
+    put_k(PIPE ? par : par ^ 1);  // PIPE: K(kt+2) over K(kt), last read in iteration kt-1; else K(kt+1)
+    put_v(par ^ 1);   // V(kt+1): image `par^1` held V(kt-1), last read in iteration kt-1
+    fetch_k();        // K(kt+3)
+    fetch_v();        // V(kt+2)
+    if constexpr (PIPE) {
+      if (kt + 1 < ntiles) qk(par ^ 1, snext);
+    } else {
+      qk(par, sacc);  // d > 80: a second score set does not fit the register file
+    }
+
+    f16x8 pf[QF][4];
+#pragma unroll
+    for (int j = 0; j < QF; ++j) {
+      // lane holds, for query lr of fragment j, keys  f*32 + (r&3) + 8*(r>>2) + 4*hi
+      if (kbase + KT > p.Lk) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kbase + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= p.Lk) sacc[j][f][r] = -INFINITY;
+          }
+      }
+      float mx = max3f(sacc[j][0][0], sacc[j][0][1], sacc[j][0][2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mx = max3f(mx, sacc[j][0][r], sacc[j][0][r + 1]);
+      mx = max3f(mx, sacc[j][0][15], sacc[j][1][0]);
+#pragma unroll
+      for (int r = 1; r < 15; r += 2) mx = max3f(mx, sacc[j][1][r], sacc[j][1][r + 1]);
+      mx = fmaxf(mx, sacc[j][1][15]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[j], mx * p.c);  // every tile has >= 1 valid key, so m_new is finite
+      const bool moved = m_new != m_run[j];
+      const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);  // first tile: exp2(-inf) = 0
+      m_run[j] = m_new;
+      float lsum = 0.f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 e2 = __builtin_elementwise_fma((f32x2){sacc[j][f][r], sacc[j][f][r + 1]}, (f32x2){p.c, p.c},
+                                                     (f32x2){-m_new, -m_new});  // v_pk_fma_f32
+          const float p0 = __builtin_amdgcn_exp2f(e2[0]);
+          const float p1 = __builtin_amdgcn_exp2f(e2[1]);
+          if (!ones_row) lsum += p0 + p1;
+          const auto pk = __builtin_amdgcn_cvt_pkrtz(p0, p1);  // v_cvt_pkrtz_f16_f32: two f16 in one VALU op
+          pf[j][f * 2 + (r >> 3)][r & 7] = (f16)pk[0];
+          pf[j][f * 2 + (r >> 3)][(r & 7) + 1] = (f16)pk[1];
+        }
+      if (__any(moved)) {  // wave-uniform: once the running max has settled the accumulators are left alone
+        l_run[j] *= alpha;
+#pragma unroll
+        for (int f = 0; f < DF; ++f)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[j][f][e] *= alpha;
+      }
+      l_run[j] += lsum;
+    }
+
+    // ---- O^T += V^T P^T : 4 steps of 16 keys.  The A fragment (head-dim rows x 8 keys per lane) is two
+    // transpose reads of the row-major V image: keys 16 st + 4 hi + {0..3} and + 8 + {0..3}, the order P holds.
 #pragma unroll
     for (int f = 0; f < DF; ++f)
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        const f16x8 vf = *(const f16x8*)(sVt + (f * 32 + lr) * VP + st * 16 + hi * 8);
-        oacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], oacc[f], 0, 0, 0);
+        const f16* vp = sV + par * SV + v_rd + (16 * st) * VR + 32 * f;
+        union { s16x4 h[2]; f16x8 v; } vf;
+        vf.h[0] = lds_read_tr16(vp);
+        vf.h[1] = lds_read_tr16(vp + 8 * VR);
+#pragma unroll
+        for (int j = 0; j < QF; ++j) oacc[j][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.v, pf[j][st], oacc[j][f], 0, 0, 0);
       }
+  };
+
+  if constexpr (PIPE) {
+    for (int kt = 0; kt < ntiles; kt += 2) {
+      step(kt, s_even, s_odd);
+      if (kt + 1 < ntiles) step(kt + 1, s_odd, s_even);
+    }
+  } else {
+    for (int kt = 0; kt < ntiles; ++kt) step(kt, s_even, s_even);
   }
 
-  float l_tot;
-  if (ones_row) {
-    // row d of O^T: fragment d/32, register ((d%32)/8)*4, in the hi = 0 half of the wave
-    float l0 = 0.f;
 #pragma unroll
-    for (int f = 0; f < DF; ++f)
+  for (int j = 0; j < QF; ++j) {
+    float l_tot;
+    if (ones_row) {
+      // row d of O^T: fragment d/32, register ((d%32)/8)*4, in the hi = 0 half of the wave
+      float l0 = 0.f;
 #pragma unroll
-      for (int rr = 0; rr < 16; rr += 4)
-        if (f * 32 + rr * 2 == p.d) l0 = oacc[f][rr];
-    l_tot = __shfl(l0, lr, 64);
-  } else {
-    l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  }
-  const float inv = 1.f / l_tot;
-  if (q_ok) {
-    f16* ob = p.O + ((size_t)b * p.Lq + q) * p.ldo + h * p.d;
+      for (int f = 0; f < DF; ++f)
 #pragma unroll
-    for (int f = 0; f < DF; ++f)
+        for (int rr = 0; rr < 16; rr += 4)
+          if (f * 32 + rr * 2 == p.d) l0 = oacc[j][f][rr];
+      l_tot = __shfl(l0, lr, 64);
+    } else {
+      l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
+    }
+    const float inv = 1.f / l_tot;
+    const int q = q0 + 32 * j;
+    if (q < p.Lq) {
+      f16* ob = p.O + ((size_t)b * p.Lq + q) * p.ldo + h * p.d;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dd = f * 32 + 8 * g + 4 * hi;
-        if (dd < p.d) {
-          f16x4 o = {(f16)(oacc[f][4 * g] * inv), (f16)(oacc[f][4 * g + 1] * inv),
-                     (f16)(oacc[f][4 * g + 2] * inv), (f16)(oacc[f][4 * g + 3] * inv)};
-          *(f16x4*)(ob + dd) = o;
+      for (int f = 0; f < DF; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = f * 32 + 8 * g + 4 * hi;
+          if (dd < p.d) {
+            f16x4 o = {(f16)(oacc[j][f][4 * g] * inv), (f16)(oacc[j][f][4 * g + 1] * inv),
+                       (f16)(oacc[j][f][4 * g + 2] * inv), (f16)(oacc[j][f][4 * g + 3] * inv)};
+            *(f16x4*)(ob + dd) = o;
+          }
         }
-      }
+    }
   }
 }
 
@@ -226,9 +313,9 @@ template <int DS>
 int launch_flash(const AttnArgs& a, hipStream_t stream) {
   constexpr int DF = (DS + 1) / 2;
   constexpr int KP = 16 * DS + 8;
-  const size_t lds = (size_t)(KT * KP + 32 * DF * VP) * sizeof(f16);
+  const size_t lds = (size_t)2 * (KT * KP + KT * v_row_halfs(DF)) * sizeof(f16);  // ping-pong K and V images
   dim3 grid((a.Lq + 127) / 128, a.heads, a.batch);
-  hipLaunchKernelGGL(flash_attn_kernel<DS>, grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5)>), grid, dim3(256), lds, stream, a);
   return rcdm_check_launch();
 }
 
@@ -349,6 +436,8 @@ int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const
   if (d->batch <= 0 || d->heads <= 0 || d->Lq <= 0 || d->Lk <= 0 || d->d <= 0) return RCDM_EINVAL;
   if ((d->d & 7) || d->d > 160) return RCDM_ESHAPE;
   if ((d->ldq & 7) || (d->ldk & 7) || (d->ldv & 7) || (d->ldo & 3)) return RCDM_ESHAPE;
+  // K/V rows of one (batch, head) are addressed with 32-bit byte offsets (raw buffer loads)
+  if ((size_t)(d->Lk + 4 * 64) * (size_t)(d->ldk > d->ldv ? d->ldk : d->ldv) * 2 >= 0x7FFFFFFFull) return RCDM_ESHAPE;
   AttnArgs a;
   a.Q = (const f16*)Q; a.K = (const f16*)K; a.V = (const f16*)V; a.O = (f16*)out;
   a.batch = d->batch; a.heads = d->heads; a.Lq = d->Lq; a.Lk = d->Lk; a.d = d->d; a.dch = d->d / 8;

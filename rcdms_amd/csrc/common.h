@@ -10,10 +10,12 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 union Pack16 {  // one 16-byte global/LDS transaction seen as 8 halves
   uint4 u;
+  u32x4 v;
   f16x8 h;
   f16 e[8];
 };

@@ -100,7 +100,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n,
   *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
 }
 
-template <int TAPS, int BM_, int BN_, int WM, int WN>
+template <int TAPS, int BM_, int BN_, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmArgs p) {
   constexpr int NW = WM * WN;             // waves
   constexpr int FM = BM_ / WM / 32;       // pixel fragments per wave
@@ -227,28 +227,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
   int cm0, cn0;               // tile being computed
   tile_of(0, cm0, cn0);
   setup_loader(cm0, cn0);
-  issue(ks_begin, 0);
-  int i_tile = 0, i_ks = 1;   // next (tile, k-step) to issue
   const int total = my_tiles * nkl;
-  int c_ks = 0, c_tile = 0;   // k-step / tile being computed
-
-  for (int g = 0; g < total; ++g) {
-    // this wave's DMA pieces of step g have landed; the barrier makes everybody's visible and also guarantees
-    // every wave is done reading the other stage (step g-1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (g + 1 < total) {
-      if (i_ks == nkl) {
-        i_ks = 0;
-        ++i_tile;
-        int im0, in0;
-        tile_of(i_tile, im0, in0);
-        setup_loader(im0, in0);
-      }
-      issue(ks_begin + i_ks, (g + 1) & 1);
-      ++i_ks;
+  int i_tile = 0, i_ks = 0;   // next (tile, k-step) to issue
+  int i_stage = 0;            // ring slot the next issue goes to
+  auto issue_next = [&]() __attribute__((always_inline)) {
+    if (i_ks == nkl) {
+      i_ks = 0;
+      ++i_tile;
+      int im0, in0;
+      tile_of(i_tile, im0, in0);
+      setup_loader(im0, in0);
     }
-    const char* sb = smem + (g & 1) * STAGE_BYTES;
+    issue(ks_begin + i_ks, i_stage);
+    ++i_ks;
+    i_stage = i_stage + 1 == NSTAGE ? 0 : i_stage + 1;
+  };
+  // prologue: NSTAGE-1 steps in flight
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < total) issue_next();
+  int c_ks = 0, c_tile = 0;   // k-step / tile being computed
+  int c_stage = 0;            // ring slot being computed
+  bool drain = false;         // epilogue stores are in flight: vmcnt counts them too, so wait for everything once
+
+  constexpr int PIECES = AI + BI;  // DMA instructions per wave per step
+  for (int g = 0; g < total; ++g) {
+    // this wave's DMA pieces of step g have landed (loads retire in order: at most the pieces of the NSTAGE-2
+    // younger steps may still be in flight); the barrier makes everybody's visible and also guarantees every
+    // wave is done reading the slot of step g-1, which the issue below refills
+    const int younger = min(NSTAGE - 2, total - 1 - g);
+    if (drain || younger <= 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (NSTAGE >= 4 && younger >= 2) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 4 ? 2 * PIECES : 0) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 3 ? PIECES : 0) : "memory");
+    }
+    drain = false;
+    __builtin_amdgcn_s_barrier();
+    if (g + NSTAGE - 1 < total) issue_next();
+    const char* sb = smem + c_stage * STAGE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       f16x8 wf[FN], xf[FM];
@@ -262,11 +280,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
         for (int j = 0; j < FM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
+    const int e_stage = c_stage;  // slot just consumed
+    c_stage = c_stage + 1 == NSTAGE ? 0 : c_stage + 1;
     if (++c_ks < nkl) continue;
     long long te0 = 0;
     if (p.trace) te0 = __builtin_amdgcn_s_memtime();
 
-    // ---- tile done: epilogue.  The stage just consumed (g&1) is idle until step g+2 is issued after the next
+    // ---- tile done: epilogue.  The slot just consumed is idle until step g+NSTAGE is issued after the next
     // barrier, so it serves as the fp32 staging tile ([RP rows][BN] floats, 16-B chunks XOR-swizzled by row) for a
     // coalesced 16-byte-per-lane store phase; the DMA of the next tile's first step keeps flowing into the other
     // stage.  Raw s_barrier + lgkmcnt only: a __syncthreads() here would drain that DMA (vmcnt(0)).
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
       constexpr int RP = (STAGE_BYTES / (BN_ * 4)) >= 64 ? 64 : 32;   // rows per pass
       constexpr int NPASS = BM_ / RP;
       constexpr int NT = NW * 64;
-      float* sC = (float*)(smem + (g & 1) * STAGE_BYTES);
+      float* sC = (float*)(smem + e_stage * STAGE_BYTES);
       // plain (non split-K, non GEGLU) tiles: every global read of the WHOLE tile's epilogue (residual rows,
       // row-vector slices, bias) is issued here, before the first staging barrier, so the round trips overlap the
       // LDS staging instead of serialising one dependent load per output chunk
@@ -414,6 +434,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     ++c_tile;
+    drain = true;
     if (c_tile < my_tiles) tile_of(c_tile, cm0, cn0);
     if (p.trace) ts_epi += __builtin_amdgcn_s_memtime() - te0;
   }
@@ -461,10 +482,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
   }
 }
 
-// variant: 1 = 128x128, 2 = 256x256  (-1 = heuristic)
+// variant: 1 = 128x128 two-slot ring x 2 blocks/CU, 2 = 256x256, 3 = 128x128 four-slot ring x 1 block/CU  (-1 = heuristic)
 int g_force_variant = -1;
 struct TileCfg { int bm, bn, blocks_per_cu; };
-const TileCfg kTiles[3] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}};
+const TileCfg kTiles[4] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}, {128, 128, 1}};
 int g_num_cus = 0;
 long long* g_trace = nullptr;
 
@@ -486,6 +507,7 @@ int pick_variant(const IgemmArgs& a) {
     g_force_variant = 99;
     if (e && !strcmp(e, "dma128")) g_force_variant = 1;
     if (e && !strcmp(e, "dma256")) g_force_variant = 2;
+    if (e && !strcmp(e, "dma128d")) g_force_variant = 3;
   }
   if (g_force_variant != 99) return g_force_variant == 0 ? 1 : g_force_variant;
   // measured (tools/kbench.py, tools/splitk_test.py, MI355X): 128x128 tiles with two blocks per CU win on every
@@ -544,12 +566,14 @@ void set_lds(K kernel, int bytes) {
 
 template <int TAPS>
 int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  constexpr int LDS_128 = 2 * (128 + 128) * 128;  // 64 KB  (two blocks per CU)
-  constexpr int LDS_256 = 2 * (256 + 256) * 128;  // 128 KB
+  constexpr int LDS_128 = 2 * (128 + 128) * 128;   // 64 KB  (two blocks per CU)
+  constexpr int LDS_128D = 4 * (128 + 128) * 128;  // 128 KB (one block per CU, three steps in flight)
+  constexpr int LDS_256 = 2 * (256 + 256) * 128;   // 128 KB
   static bool attr_set = false;
   if (!attr_set) {
-    set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2>, LDS_128);
-    set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4>, LDS_256);
+    set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2>, LDS_128);
+    set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 4>, LDS_128D);
+    set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2>, LDS_256);
     attr_set = true;
   }
   if (a.splits > 1) {
@@ -575,9 +599,11 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   if (gx > ntiles) gx = ntiles;
   dim3 grid(gx, a.splits);
   if (variant == 2)
-    hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 256, 256, 2, 4>), grid, dim3(512), LDS_256, stream, a);
+    hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2>), grid, dim3(512), LDS_256, stream, a);
+  else if (variant == 3)
+    hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 128, 128, 2, 2, 4>), grid, dim3(256), LDS_128D, stream, a);
   else
-    hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 128, 128, 2, 2>), grid, dim3(256), LDS_128, stream, a);
+    hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2>), grid, dim3(256), LDS_128, stream, a);
   int rc = rcdm_check_launch();
   if (rc) return rc;
   if (a.splits > 1) {
@@ -617,7 +643,7 @@ int from_conv(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
 extern "C" {
 
 int rcdm_set_igemm_variant(int32_t v) {
-  if (v < -1 || v > 2) return RCDM_EINVAL;
+  if (v < -1 || v > 3) return RCDM_EINVAL;
   g_force_variant = v < 0 ? 99 : v;
   return RCDM_OK;
 }

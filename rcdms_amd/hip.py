@@ -7,7 +7,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librcdm_hip.so")
+LIB_PATH = os.environ.get("RCDM_LIB") or os.path.join(_HERE, "lib", "librcdm_hip.so")  # RCDM_LIB: kernel experiments
 
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
 
