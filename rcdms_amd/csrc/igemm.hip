@@ -482,10 +482,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
   }
 }
 
-// variant: 1 = 128x128 two-slot ring x 2 blocks/CU, 2 = 256x256, 3 = 128x128 four-slot ring x 1 block/CU  (-1 = heuristic)
+// variant: 1 = 128x128 (2 blocks/CU), 2 = 256x256 (1), 3 = 64x64 two-slot ring (4), 4 = 64x64 four-slot ring (2),
+// 5 = 128x64 (3)   (-1 = heuristic)
 int g_force_variant = -1;
 struct TileCfg { int bm, bn, blocks_per_cu; };
-const TileCfg kTiles[4] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}, {128, 128, 1}};
+const TileCfg kTiles[6] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}, {64, 64, 4}, {64, 64, 2}, {128, 64, 3}};
 int g_num_cus = 0;
 long long* g_trace = nullptr;
 
@@ -507,11 +508,20 @@ int pick_variant(const IgemmArgs& a) {
     g_force_variant = 99;
     if (e && !strcmp(e, "dma128")) g_force_variant = 1;
     if (e && !strcmp(e, "dma256")) g_force_variant = 2;
-    if (e && !strcmp(e, "dma128d")) g_force_variant = 3;
+    if (e && !strcmp(e, "dma64")) g_force_variant = 3;
   }
   if (g_force_variant != 99) return g_force_variant == 0 ? 1 : g_force_variant;
-  // measured (tools/kbench.py, tools/splitk_test.py, MI355X): 128x128 tiles with two blocks per CU win on every
-  // shape of this UNet once split-K is planned per plan_splits(); 256x256 stays available as variant 2.
+  // measured (tools/kbench.py, MI355X).  128x128 with two blocks per CU is the default.  Shapes that leave most CUs
+  // without a 128x128 tile (8x8 / 16x16 levels, context K/V projections) run as 64x64 or 128x64 tiles so that several
+  // blocks per CU keep more DMA in flight; N = 320 / 960 (half a 128-wide tile wasted) with a short K take 128x64;
+  // the deep-K convs of the 32x32 / 16x16 levels take 256x256.
+  const int nk = (a.Cin + BK - 1) / BK * (a.Ktot / a.Cin);
+  if (a.Ktot != a.Cin) return (a.M >= 2560 && a.M <= 10240 && nk >= 120) ? 2 : 1;
+  const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+  if (t128 <= 64 && nk <= 24) return 4;
+  if (t128 <= 160) return nk >= 40 ? 5 : 3;
+  if (t128 <= 256) return 5;
+  if ((a.N % 128) == 64 && nk <= 10) return 5;
   return 1;
 }
 
@@ -567,13 +577,17 @@ void set_lds(K kernel, int bytes) {
 template <int TAPS>
 int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   constexpr int LDS_128 = 2 * (128 + 128) * 128;   // 64 KB  (two blocks per CU)
-  constexpr int LDS_128D = 4 * (128 + 128) * 128;  // 128 KB (one block per CU, three steps in flight)
   constexpr int LDS_256 = 2 * (256 + 256) * 128;   // 128 KB
+  constexpr int LDS_64 = 2 * (64 + 64) * 128;      // 32 KB
+  constexpr int LDS_64D = 4 * (64 + 64) * 128;     // 64 KB  (three steps in flight)
+  constexpr int LDS_128x64 = 2 * (128 + 64) * 128; // 48 KB
   static bool attr_set = false;
   if (!attr_set) {
     set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2>, LDS_128);
-    set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 4>, LDS_128D);
     set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2>, LDS_256);
+    set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2>, LDS_64);
+    set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4>, LDS_64D);
+    set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2>, LDS_128x64);
     attr_set = true;
   }
   if (a.splits > 1) {
@@ -598,12 +612,13 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   if (persist_mode == 0 || (persist_mode == 2 && (a.epi & RCDM_EPI_GEGLU))) gx = ntiles;
   if (gx > ntiles) gx = ntiles;
   dim3 grid(gx, a.splits);
-  if (variant == 2)
-    hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2>), grid, dim3(512), LDS_256, stream, a);
-  else if (variant == 3)
-    hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 128, 128, 2, 2, 4>), grid, dim3(256), LDS_128D, stream, a);
-  else
-    hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2>), grid, dim3(256), LDS_128, stream, a);
+  switch (variant) {
+    case 2: hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2>), grid, dim3(512), LDS_256, stream, a); break;
+    case 3: hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2>), grid, dim3(256), LDS_64, stream, a); break;
+    case 4: hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4>), grid, dim3(256), LDS_64D, stream, a); break;
+    case 5: hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2>), grid, dim3(256), LDS_128x64, stream, a); break;
+    default: hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2>), grid, dim3(256), LDS_128, stream, a);
+  }
   int rc = rcdm_check_launch();
   if (rc) return rc;
   if (a.splits > 1) {
@@ -643,7 +658,7 @@ int from_conv(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
 extern "C" {
 
 int rcdm_set_igemm_variant(int32_t v) {
-  if (v < -1 || v > 3) return RCDM_EINVAL;
+  if (v < -1 || v > 5) return RCDM_EINVAL;
   g_force_variant = v < 0 ? 99 : v;
   return RCDM_OK;
 }

@@ -59,7 +59,7 @@ def ws(nbytes):
     (130, 72, 200, 1 | 4, 3),        # forced split-K, K tail (200 = 3*64 + 8), N % 128 != 0
     (1024, 960, 320, 0, 1),
 ])
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_gemm(hiplib, M, N, K, epi, split, variant):
     from rcdms_amd import hip
     hip.set_igemm_variant(variant)
@@ -108,7 +108,7 @@ def test_gemm_transpose_detecting(hiplib):
     close(out, W.t(), rel=1e-3, abs_frac=1e-3)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("split", [1, 2])
 def test_gemm_geglu(hiplib, split, variant):
     from rcdms_amd import hip
@@ -141,7 +141,7 @@ def test_gemm_geglu(hiplib, split, variant):
     (1, 5, 8, 8, 128, 64, 1, 1, 1),     # Upsample3D folded into the conv
     (2, 1, 8, 8, 320, 320, 1, 0, 4),    # split-K
 ])
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split, variant):
     from rcdms_amd import hip
     hip.set_igemm_variant(variant)

@@ -40,6 +40,14 @@ GEMMS = [  # (name, M, N, K, epi)
     ("L2 CxC K=1280", 2560, 1280, 1280, 5),
     ("L2 geglu N=10240", 2560, 10240, 1280, 9),
     ("L2 ff-out K=5120", 2560, 1280, 5120, 5),
+    ("L2 qkv N=3840", 2560, 3840, 1280, 0),
+    ("L3 CxC K=1280", 640, 1280, 1280, 5),
+    ("L3 qkv N=3840", 640, 3840, 1280, 0),
+    ("L3 geglu N=10240", 640, 10240, 1280, 9),
+    ("L3 ff-out K=5120", 640, 1280, 5120, 5),
+    ("L1 ctx kv N=1280 K=768", 850, 1280, 768, 0),
+    ("L2 ctx kv N=2560 K=768", 850, 2560, 768, 0),
+    ("L1 qkv N=1920", 10240, 1920, 640, 0),
 ]
 CONVS = [  # (name, n_img, H, W, cin, cout)
     ("L0 320->320 @64", 10, 64, 64, 320, 320),
