@@ -519,7 +519,8 @@ int pick_variant(const IgemmArgs& a) {
   if (a.Ktot != a.Cin) return (a.M >= 2560 && a.M <= 10240 && nk >= 120) ? 2 : 1;
   const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
   if (t128 <= 64 && nk <= 24) return 4;
-  if (t128 <= 160) return nk >= 40 ? 5 : 3;
+  if (nk >= 40) return 1;  // deep K: split-K over 128x128 tiles fills the chip
+  if (t128 <= 160) return 3;
   if (t128 <= 256) return 5;
   if ((a.N % 128) == 64 && nk <= 10) return 5;
   return 1;

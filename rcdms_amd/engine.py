@@ -56,6 +56,7 @@ class Plan:
         self.device = torch.device(device)
         self.bufs = {}
         self.ops = []
+        self.tags = []  # one label per op (kind + shape): tools/opprof.py aggregates per-op timings by it
         self.keep = []  # tensors that must outlive the plan (packed weights etc.)
         self.n_launch = 0
 
@@ -86,8 +87,9 @@ class Plan:
     def total_bytes(self):
         return sum(b.nbytes for b in self.bufs.values())
 
-    def add(self, fn):
+    def add(self, fn, tag="misc"):
         self.ops.append(fn)
+        self.tags.append(tag)
 
     def run(self, ops=None):
         for op in (self.ops if ops is None else ops):
@@ -118,7 +120,7 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
     def op():
         hip.gemm(d, A.ptr, Wt.data_ptr(), bptr, (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0,
                  residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
-    plan.add(op)
+    plan.add(op, f"gemm M={A.M} N={N} K={K} epi={epi}")
     plan.keep += [Wt, bias, rv_t]
     plan.n_launch += 2 if wsb else 1
 
@@ -142,7 +144,7 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
     def op():
         hip.conv3x3(d, x.ptr, Wt.data_ptr(), bptr, (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0,
                     residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
-    plan.add(op)
+    plan.add(op, f"conv3x3 {n_img}x{H}x{W} {cin}->{cout} s={stride} up={up} epi={epi}")
     plan.keep += [Wt, bias, rv_t]
     plan.n_launch += 2 if wsb else 1
 
@@ -153,7 +155,7 @@ def emit_groupnorm(plan, x, samples, rows_per_sample, gamma, beta, eps, silu, ou
 
     def op():
         hip.groupnorm_silu(d, x.ptr, gamma.data_ptr(), beta.data_ptr(), out.ptr, ws.ptr, ws.nbytes)
-    plan.add(op)
+    plan.add(op, f"groupnorm S={samples} R={rows_per_sample} C={x.C} silu={int(silu)}")
     plan.keep += [gamma, beta]
     plan.n_launch += 3
 
@@ -163,7 +165,7 @@ def emit_layernorm(plan, x, gamma, beta, out, pe=None, rows_per_frame=1, frames=
 
     def op():
         hip.layernorm(d, x.ptr, gamma.data_ptr(), beta.data_ptr(), pe.data_ptr() if pe is not None else 0, out.ptr)
-    plan.add(op)
+    plan.add(op, f"layernorm M={x.M} C={x.C} pe={int(pe is not None)}")
     plan.keep += [gamma, beta, pe]
     plan.n_launch += 1
 
@@ -173,7 +175,7 @@ def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out):
 
     def op():
         hip.flash_attn(d, q.ptr, k.ptr, v.ptr, out.ptr)
-    plan.add(op)
+    plan.add(op, f"flash_attn B={batch} H={heads} Lq={Lq} Lk={Lk} d={d_head}")
     plan.n_launch += 1
 
 
@@ -182,7 +184,7 @@ def emit_temporal_attn(plan, qkv, samples, frames, pixels, heads, d_head, out):
 
     def op():
         hip.temporal_attn(d, qkv.ptr, out.ptr)
-    plan.add(op)
+    plan.add(op, f"temporal_attn S={samples} F={frames} P={pixels} H={heads} d={d_head}")
     plan.n_launch += 1
 
 
