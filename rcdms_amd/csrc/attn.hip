@@ -341,18 +341,22 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs p) {
   const long total_px = (long)p.samples * p.pixels;
   const long px0 = (long)blockIdx.x * p.tpb;
 
-  // ---- stage: chunk id -> (pl, f, c) ------------------------------------------------------------------
-  const int nchunks = p.tpb * F * rowc;
-  for (int id = t; id < nchunks; id += 256) {
-    const int c = id % rowc, r = id / rowc;
+  // ---- stage: a wave takes whole rows (pl, f), its lanes the row's 16-B chunks: the row -> address arithmetic
+  // (divisions by runtime values) happens once per row on wave-uniform values, not once per chunk
+  const int lane = t & 63, wave = t >> 6;
+  const int nrows = p.tpb * F;
+  for (int r = wave; r < nrows; r += 4) {
     const int f = r % F, pl = r / F;
-    const long px = px0 + pl;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (px < total_px) {
-      const long b = px / p.pixels, pix = px - b * p.pixels;
-      v = *(const uint4*)(p.qkv + ((b * F + f) * p.pixels + pix) * (long)p.ldqkv + c * 8);
+    const int px = (int)px0 + pl;
+    const bool ok = px < (int)total_px;
+    const int b = ok ? px / p.pixels : 0, pix = px - b * p.pixels;
+    const f16* src = p.qkv + ((long)(b * F + f) * p.pixels + pix) * (long)p.ldqkv;
+    f16* dst = tile + (size_t)r * C3;
+    for (int c = lane; c < rowc; c += 64) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *(const uint4*)(src + c * 8);
+      *(uint4*)(dst + c * 8) = v;
     }
-    *(uint4*)(tile + (size_t)r * C3 + c * 8) = v;
   }
   __syncthreads();
 
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs p) {
       s[j] = __expf(s[j] - mx);
       sum += s[j];
     }
-    const float inv = 1.f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);
     for (int c = 0; c < p.d; c += 8) {
       float o[8];
 #pragma unroll
@@ -414,15 +418,14 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs p) {
 
   // ---- store the [0, C) columns of every staged row as whole rows -----------------------------------------
   const int outc = C / 8;
-  const int nout = p.tpb * F * outc;
-  for (int id = t; id < nout; id += 256) {
-    const int c = id % outc, r = id / outc;
+  for (int r = wave; r < nrows; r += 4) {
     const int f = r % F, pl = r / F;
-    const long px = px0 + pl;
-    if (px < total_px) {
-      const long b = px / p.pixels, pix = px - b * p.pixels;
-      *(uint4*)(p.out + ((b * F + f) * p.pixels + pix) * (long)p.ldo + c * 8) =
-          *(const uint4*)(tile + (size_t)r * C3 + c * 8);
+    const int px = (int)px0 + pl;
+    if (px < (int)total_px) {
+      const int b = px / p.pixels, pix = px - b * p.pixels;
+      f16* dst = p.out + ((long)(b * F + f) * p.pixels + pix) * (long)p.ldo;
+      const f16* srow = tile + (size_t)r * C3;
+      for (int c = lane; c < outc; c += 64) *(uint4*)(dst + c * 8) = *(const uint4*)(srow + c * 8);
     }
   }
 }

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
       bt[i][4 + e] = b1[e];
     }
   }
+  const float invC = 1.0f / (float)C;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int row = row0 + r;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
         v[i][e] = (float)raw[r][i].e[e];
         sum += v[i][e];
       }
-    const float mean = wave_sum(sum) / (float)C;
+    const float mean = wave_sum(sum) * invC;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
         }
       }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    const float rstd = rsqrtf(wave_sum(sq) * invC + eps);
     if (row < M) {
       const float* pe_row = pe ? pe + (size_t)((row / rows_per_frame) % frames) * C : nullptr;
 #pragma unroll
