@@ -2,7 +2,7 @@
 REFERENCE's own model classes (imported from /root/reference through oracle/ref_scaffold.py) on CPU fp32
 with procedural name-seeded weights (rcdms_amd/synth.py).  Run in the build container only:
 
-    python -m oracle.make_golden [--full]      # --full adds the full-width UNet at 32x32 and 64x64 latents
+    python -m oracle.make_golden [--full] [--only blocks|tiny|ctx|full]   # --full adds the full-width UNet (32x32, 64x64)
 
 What is stored: small inputs and the reference outputs (fp32 .npz), plus a digest of the reference's
 state-dict key/shape list so the mirrored classes are checked to have the identical 1286-key layout.
@@ -129,6 +129,22 @@ def full_unet():
         save(f"unet_full_{hw}", t=np.int64(t), y=y, digest=dig)
 
 
+@torch.no_grad()
+def ctx_stacks():
+    """The driver's fine_stack / semantic_stack (stage2_batchtest_rcdms_model.py:117-149) at the shapes the pipeline
+    feeds them for mask [1,0,0,0,0] with CFG: 2 seen rows x 257 patch tokens x 1664, 8 unseen rows x 1 x 1280."""
+    fine_cls, sem_cls = ref_scaffold.load_reference_context_stacks()
+    for name, cls, vis_dim, k, lv, seed in (("ctx_fine", fine_cls, 1664, 2, 257, 301),
+                                            ("ctx_semantic", sem_cls, 1280, 8, 1, 302),
+                                            ("ctx_fine_ragged", fine_cls, 1664, 3, 70, 303)):
+        m = cls(text_dim=768, vis_dim=vis_dim).eval()
+        digest = load_procedural(m, seed)
+        vis = synth.normal_tensor(name + ".vis", (k, lv, vis_dim), seed)   # inputs are regenerated by the tests
+        text = synth.normal_tensor(name + ".text", (k, 85, 768), seed)
+        out = m(vis, text)
+        save(name, out=out, seed=seed, k=k, lv=lv, vis_dim=vis_dim, key_digest=digest)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -139,5 +155,7 @@ if __name__ == "__main__":
         print("blocks"); blocks()
     if a.only in ("", "tiny"):
         print("tiny UNet"); tiny_unet()
+    if a.only in ("", "ctx"):
+        print("context stacks"); ctx_stacks()
     if a.full or a.only == "full":
         print("full UNet"); full_unet()

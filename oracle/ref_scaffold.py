@@ -207,3 +207,57 @@ def build_reference_unet(width=None, cross_dim=None, layers_per_block=None):
         cfg["layers_per_block"] = layers_per_block
     model = ref_unet.UNet3DConditionModel.from_config(cfg, **TESTING_YAML_UNET_KWARGS)
     return model.eval()
+
+
+def load_reference_context_stacks():
+    """Import the reference driver stage2_batchtest_rcdms_model.py (its `fine_stack` / `semantic_stack` classes,
+    :117-149, live there, not under src/) as module `refdriver` and return (fine_stack, semantic_stack).
+    The script's unrelated top-level imports that this container lacks (cv2, omegaconf, skimage, h5py,
+    torchvision.transforms, transformers' CLIP classes, diffusers model/scheduler classes) are satisfied with empty placeholders: none of them
+    is touched by the two classes, which are nn.Linear + torch.nn.MultiheadAttention.  Its `from src...` imports are
+    pointed at the reference package (alias refsrc) with the pipeline module replaced by a placeholder, because
+    RCDMs_pipeline.py needs the real diffusers."""
+    if "refdriver" in sys.modules:
+        m = sys.modules["refdriver"]
+        return m.fine_stack, m.semantic_stack
+    load_reference_models()
+    d = sys.modules["diffusers"]
+    for name in ("AutoencoderKL", "DDPMScheduler", "UNet2DConditionModel", "DDIMScheduler"):
+        if not hasattr(d, name):
+            setattr(d, name, type(name, (), {}))
+    placeholders = {
+        "cv2": {}, "h5py": {}, "omegaconf": {"OmegaConf": type("OmegaConf", (), {})},
+        "skimage": {}, "skimage.metrics": {"structural_similarity": None},
+        "torchvision.transforms": {},
+    }
+    saved = {}
+    for name, attrs in placeholders.items():
+        if name not in sys.modules:
+            _mod(name, **attrs)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    # the driver says `from src.models.unet import ...` / `from src.pipelines.RCDMs_pipeline import RCDMsPipeline`
+    for k in ("src", "src.models", "src.models.unet", "src.pipelines", "src.pipelines.RCDMs_pipeline", "transformers"):
+        saved[k] = sys.modules.get(k)
+    try:
+        # the installed transformers refuses to import beside the spec-less torchvision placeholder; the driver only
+        # names six of its classes at import time
+        _mod("transformers", **{n: type(n, (), {}) for n in (
+            "CLIPVisionModelWithProjection", "CLIPTextModelWithProjection", "CLIPVisionModel", "CLIPImageProcessor",
+            "CLIPTextModel", "CLIPTokenizer")})
+        importlib.import_module("refsrc.models.unet")
+        sys.modules["src"] = sys.modules["refsrc"]
+        sys.modules["src.models"] = sys.modules["refsrc.models"]
+        sys.modules["src.models.unet"] = sys.modules["refsrc.models.unet"]
+        _mod("src.pipelines")
+        _mod("src.pipelines.RCDMs_pipeline", RCDMsPipeline=type("RCDMsPipeline", (), {}))
+        spec = importlib.util.spec_from_file_location("refdriver", os.path.join(REF_ROOT, "stage2_batchtest_rcdms_model.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules["refdriver"] = m
+        spec.loader.exec_module(m)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return m.fine_stack, m.semantic_stack

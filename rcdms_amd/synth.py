@@ -48,6 +48,12 @@ def procedural_tensor(name, shape, seed=0):
     return torch.from_numpy(np.ascontiguousarray(x))
 
 
+def normal_tensor(name, shape, seed=0):
+    """Standard-normal test INPUT named `name` (platform-stable Philox stream, like the weights)."""
+    g = _rng(name, seed)
+    return torch.from_numpy(g.standard_normal(size=tuple(int(s) for s in shape), dtype=np.float32))
+
+
 def _is_norm_param(name):
     parts = name.split(".")
     owner = parts[-2]
