@@ -122,13 +122,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
   const int nkl = ks_end - ks_begin;
   if (my_tiles == 0 || nkl <= 0) return;
 
-  // XCD-aware tile order: block b runs on XCD b%8 -> give each XCD a contiguous run of tiles (n fastest) so
-  // tiles sharing an activation row panel are in flight on the same L2 at the same time.
+  // XCD-aware, L2-blocked tile order.  Block b runs on XCD b%8, so each XCD is given a contiguous run of the tile
+  // sequence; the sequence itself walks super-rows of GM row panels column by column (n outer, m inner inside the
+  // super-row), so the ~64 tiles an XCD has in flight form a GM x (64/GM) patch: every activation panel is shared
+  // by 64/GM tiles and every weight panel by GM tiles *at the same time*.  With plain n-fastest order a wide N
+  // (GEGLU: 40-80 column tiles) streams the whole weight matrix through the 4 MB L2 once per row panel: rocprofv3
+  // FETCH_SIZE showed 16-19x the operand bytes (0.4-0.5 GB per launch, HBM-bound) on the 32x32 / 16x16 levels.
+  constexpr int GM = 8;
   auto tile_of = [&](int i, int& m0, int& n0) __attribute__((always_inline)) {
     const int lin = (int)blockIdx.x + i * G;
     const int xcd = lin & 7, q = ntiles >> 3, r = ntiles & 7;
     const int tl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-    const int tn = tl % p.tilesN, tm = tl / p.tilesN;
+    const int per_group = GM * p.tilesN;
+    const int grp = tl / per_group, rem = tl - grp * per_group;
+    const int gm = min(GM, p.tilesM - grp * GM);  // rows in this (possibly last, short) super-row
+    const int tn = rem / gm, tm = grp * GM + (rem - tn * gm);
     m0 = tm * BM_;
     n0 = tn * BN_;
   };
@@ -173,8 +181,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
   auto issue = [&](int ks, int stage) __attribute__((always_inline)) {
     int tap = 0, kci = ks;
     if (TAPS != 1) {
-      tap = ks / p.kc;
-      kci = ks - tap * p.kc;
+      // channel chunk outer, tap inner: the nine shifted windows of one 64-channel slab are read back to back, so
+      // the re-reads hit L2 (one slab of all tiles in flight on an XCD is ~2 MB).  Tap-outer order re-read the whole
+      // Cin-deep panel (16 MB in flight at Cin = 960) per tap: FETCH_SIZE was 10x the input bytes.
+      kci = ks / 9;
+      tap = ks - kci * 9;
     }
     const int c0 = kci * BK;
     const int dy = tap / 3, dx = tap - dy * 3;
