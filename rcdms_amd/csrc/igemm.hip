@@ -276,10 +276,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     }
     drain = false;
     __builtin_amdgcn_s_barrier();
-    if (g + NSTAGE - 1 < total) issue_next();
+    // 8-wave blocks put two waves on every SIMD, released by the same barrier: if both issued their DMA pieces first
+    // (each piece stalls the issuing wave for ~100 cycles) the SIMD's matrix pipe would idle through both bursts.
+    // The second half of the block therefore issues after its first two k-chunks, under the first half's MFMAs.
+    const bool more = g + NSTAGE - 1 < total;
+    const int issue_kk = (NW == 8 && wave >= 4) ? 2 : 0;
     const char* sb = smem + c_stage * STAGE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
+      if ((kk == 0 || (NW == 8 && kk == 2)) && more && issue_kk == kk) issue_next();
       f16x8 wf[FN], xf[FM];
 #pragma unroll
       for (int i = 0; i < FN; ++i) wf[i] = *(const f16x8*)(sb + rowB + i * 32 * 128 + koff[kk]);
@@ -530,6 +535,14 @@ int pick_variant(const IgemmArgs& a) {
   if (a.Ktot != a.Cin) return (a.M >= 2560 && a.M <= 10240 && nk >= 120) ? 2 : 1;
   const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
   if (t128 <= 64 && nk <= 24) return 4;
+  if (nk >= 20 && nk < 40 && a.N >= 512 && a.M >= 512) {
+    // 256x256 (staggered 8-wave loop, ~8 % faster per flop) when its last round of tiles is not emptier than 128x128's
+    const int cus = num_cus();
+    const int t256 = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const float e1 = (float)t128 / (float)(((t128 + 2 * cus - 1) / (2 * cus)) * 2 * cus);
+    const float e2 = (float)t256 / (float)(((t256 + cus - 1) / cus) * cus);
+    if (1.08f * e2 > e1 + 0.01f) return 2;
+  }
   if (nk >= 40) return 1;  // deep K: split-K over 128x128 tiles fills the chip
   if (t128 <= 160) return 3;
   if (t128 <= 256) return 5;
