@@ -198,7 +198,8 @@ def main():
         "unit": "story-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"PororoSV stage-2, {a.latent * 8}x{a.latent * 8}, {T}-step DDIM, CFG {a.guidance}, "
+        "config": {"workload": f"{'FlintstonesSV' if a.ctx_len == 91 else 'PororoSV'} stage-2, {a.latent * 8}x{a.latent * 8}, "
+                               f"{T}-step DDIM, CFG {a.guidance}, "
                                f"batch={S} story x 5 frames per GPU, ctx {a.ctx_len}x768, random-init 1276.9M-param UNet3D",
                    "stories_per_gpu": S, "latent": a.latent, "ddim_steps": T, "parallelism": f"story-replicas x{world}"},
         "roofline": roof,

@@ -114,6 +114,26 @@ def test_full_unet_batch_independence_and_determinism(full_unet):
     assert not torch.equal(y0[1], y2[1])
 
 
+def test_full_unet_flintstones_batch4(full_unet):
+    """BASELINE config 3 shape: 4 stories with CFG (b = 8) and the FlintstonesSV context length L = 91, full width,
+    32x32 latents.  Stories are independent, so every story of the batch must reproduce the same story run
+    as a batch of one — not bitwise (tile shapes and split-K plans depend on M) but well inside the f16 tolerance."""
+    s = synth.synthetic_story(stories=4, latent_hw=(32, 32), ctx_len=91, seed=44)
+    lat2 = torch.cat([s["latents"]] * 2)                                    # [uncond x4 | cond x4]
+    x = torch.cat([lat2, s["mask"], s["masked_latents"]], dim=1).to(DEV)
+    ctx = s["ctx"].to(DEV)                                                  # (2*4*5, 91, 768)
+    with torch.no_grad():
+        y = full_unet(x, 961, ctx).clone().float().cpu()
+    assert y.shape == (8, 4, 5, 32, 32) and torch.isfinite(y).all()
+    for i in (0, 3):
+        rows = [i, 4 + i]                                                   # the two CFG halves of story i
+        xi = x[rows].contiguous()
+        ci = ctx.view(8, 5, 91, 768)[rows].reshape(10, 91, 768).contiguous()
+        with torch.no_grad():
+            yi = full_unet(xi, 961, ci).clone().float().cpu()
+        check(y[rows], yi, 3e-3, 2e-2, f"story {i} of the batch vs alone")
+
+
 def _tiny_story(S, cfg=True, seed=3):
     return synth.synthetic_story(stories=S, latent_hw=(16, 16), ctx_len=13, ctx_dim=64, cfg=cfg, seed=seed)
 
