@@ -34,15 +34,23 @@ __global__ void gn_stats_kernel(const GnArgs p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
   const f16* base = p.x + (size_t)s * p.P * p.ldx + ch * 8;
-  for (int r = r_begin + rl; r < r_end; r += p.RPB) {
-    Pack16 v;
-    v.u = *(const uint4*)(base + (size_t)r * p.ldx);
+  // four independent 16-byte loads in flight per thread; rows past r_end read as zero and add nothing
+  for (int r = r_begin + rl; r < r_end; r += 4 * p.RPB) {
+    Pack16 v[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float f = (float)v.e[e];
-      sum[e] += f;
-      sq[e] += f * f;
+    for (int u = 0; u < 4; ++u) {
+      const int ru = r + u * p.RPB;
+      v[u].u = make_uint4(0, 0, 0, 0);
+      if (ru < r_end) v[u].u = *(const uint4*)(base + (size_t)ru * p.ldx);
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)v[u].e[e];
+        sum[e] += f;
+        sq[e] += f * f;
+      }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -128,16 +136,24 @@ __global__ void gn_apply_kernel(const GnArgs p) {
   }
   const f16* xb = p.x + (size_t)s * p.P * p.ldx + ch * 8;
   f16* yb = p.y + (size_t)s * p.P * p.ldy + ch * 8;
-  for (int r = blockIdx.x * p.RPB + rl; r < p.P; r += gridDim.x * p.RPB) {
-    Pack16 v, o;
-    v.u = *(const uint4*)(xb + (size_t)r * p.ldx);
+  const int rstep = gridDim.x * p.RPB;
+  for (int r = blockIdx.x * p.RPB + rl; r < p.P; r += 4 * rstep) {
+    Pack16 v[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float f = (float)v.e[e] * sc[e] + sh[e];
-      if (p.silu) f = silu_f(f);
-      o.e[e] = (f16)f;
+    for (int u = 0; u < 4; ++u)  // four loads in flight
+      if (r + u * rstep < p.P) v[u].u = *(const uint4*)(xb + (size_t)(r + u * rstep) * p.ldx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u * rstep >= p.P) break;
+      Pack16 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v[u].e[e] * sc[e] + sh[e];
+        if (p.silu) f = silu_f(f);
+        o.e[e] = (f16)f;
+      }
+      *(uint4*)(yb + (size_t)(r + u * rstep) * p.ldy) = o.u;
     }
-    *(uint4*)(yb + (size_t)r * p.ldy) = o.u;
   }
 }
 
