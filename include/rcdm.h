@@ -38,6 +38,8 @@ extern "C" {
 #define RCDM_EPI_BIAS 1      /* + bias[n]                              (fp32 [N])                  */
 #define RCDM_EPI_ROWVEC 2    /* + rowvec[m / rows_per_sample][n]       (fp32, resnet.py:191-194)   */
 #define RCDM_EPI_RESIDUAL 4  /* + residual[m][n]                       (f16, ldr)                  */
+#define RCDM_EPI_GELU 16     /* out = gelu(acc + bias + rowvec) (+ residual): exact erf GELU, the "gelu" FeedForward of
+                             * the stage-1 prior (diffusers GELU(approximate="none")); not with GEGLU  */
 #define RCDM_EPI_GEGLU 8     /* out[m][j] = (h+bh) * gelu(g+bg); W/bias rows packed in groups of   */
                              /* 64 = 32 hidden rows then their 32 gate rows (rcdm_pack_geglu_rows) */
 
@@ -151,6 +153,12 @@ typedef struct {
 
 int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const void* V, void* out,
                     void* stream);
+/* the same with a mask: key k of batch b is visible to query q iff key_valid[b*Lk + k] != 0 (key_valid may be NULL =
+ * all valid) and, with causal != 0, k <= q.  Replaces the additive attention_mask of the stage-1 prior transformer
+ * (myprior_transformer.py:389-393: (1 - text_mask) * -10000 padded, + causal_attention_mask :250-256), whose masked
+ * probabilities are exactly 0 in fp32.  A query with no visible key yields a zero row. */
+int rcdm_flash_attn_masked(const rcdm_attn_desc* d, const void* Q, const void* K, const void* V,
+                           const unsigned char* key_valid, int32_t causal, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Temporal self-attention over the f frames of every (sample, pixel, head).

@@ -83,9 +83,10 @@ def time_embedding_mlp(sd, t_emb):
     return F.linear(F.silu(h), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
 
 
-def attention_core(q, k, v, heads):
+def attention_core(q, k, v, heads, mask=None):
     """CrossAttention.reshape_heads_to_batch_dim + _attention + reshape_batch_dim_to_heads,
-    attention.py:93-105,170-199: softmax(q k^T * d^-0.5) v per head, no mask, no upcast."""
+    attention.py:93-105,170-199: softmax(q k^T * d^-0.5 [+ mask]) v per head, no upcast.  `mask`: additive
+    (bsz, lq, lk), the same for every head (attention.py:187-188; the stage-1 prior passes 0 / -10000 entries)."""
     bsz, lq, c = q.shape
     d = c // heads
 
@@ -93,7 +94,10 @@ def attention_core(q, k, v, heads):
         return x.reshape(bsz, x.shape[1], heads, d).permute(0, 2, 1, 3)
 
     qh, kh, vh = split(q), split(k), split(v)
-    probs = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5), dim=-1)
+    scores = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
+    if mask is not None:
+        scores = scores + mask[:, None]
+    probs = torch.softmax(scores, dim=-1)
     return torch.matmul(probs, vh).permute(0, 2, 1, 3).reshape(bsz, lq, c)
 
 

@@ -27,6 +27,8 @@ struct AttnArgs {
   int batch, heads, Lq, Lk, d, dch;
   int ldq, ldk, ldv, ldo;
   float c;  // scale * log2(e)
+  const unsigned char* kvalid;  // MASKED: [batch][Lk], 0 = key padded out (NULL = all valid)
+  int causal;                   // MASKED: key k visible to query q only if k <= q
 };
 
 // V row stride in LDS (halfs) for 32*DF padded columns: the smallest >= 64*DF bytes whose dword stride is 16 or 48
@@ -50,7 +52,9 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // ~4 VALU ops per score: raw v_exp_f32, v_max3 row max, packed RTZ f16 conversion, the row SUM taken from a
 // ones-row appended to V^T (it falls out of the PV MFMA, consistently with the rounded P), the O rescale skipped
 // while the running max does not move, and all K/V staging index math hoisted out of the key-tile loop.
-template <int DS, int QF, bool PIPE>  // d padded to 16*DS for QK^T and to 32*DF for PV; a wave owns QF fragments of 32 queries
+// MASKED: causal and/or key-padding mask (the stage-1 prior transformer's additive -10000 mask, myprior_transformer.py:
+// 389-393: a masked score contributes exp(-10000) = 0 in fp32, so masking hard to -inf is the same result).
+template <int DS, int QF, bool PIPE, bool MASKED>  // d padded to 16*DS for QK^T and to 32*DF for PV; a wave owns QF fragments of 32 queries
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
   constexpr int DF = (DS + 1) / 2;
   constexpr int KP = 16 * DS + 8;  // halfs per K row
@@ -206,7 +210,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
 #pragma unroll
     for (int j = 0; j < QF; ++j) {
       // lane holds, for query lr of fragment j, keys  f*32 + (r&3) + 8*(r>>2) + 4*hi
-      if (kbase + KT > p.Lk) {
+      if constexpr (MASKED) {
+        // validity of the tile's 64 keys as one wave-uniform 64-bit mask (lane i looks at key kbase + i)
+        bool kv = kbase + lane < p.Lk;
+        if (kv && p.kvalid) kv = p.kvalid[(size_t)b * p.Lk + kbase + lane] != 0;
+        const unsigned long long vmask = __ballot(kv);
+        const int qq = q0 + 32 * j;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool vis = ((vmask >> kl) & 1ull) && !(p.causal && kbase + kl > qq);
+            if (!vis) sacc[j][f][r] = -INFINITY;
+          }
+      } else if (kbase + KT > p.Lk) {
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -223,7 +241,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
       for (int r = 1; r < 15; r += 2) mx = max3f(mx, sacc[j][1][r], sacc[j][1][r + 1]);
       mx = fmaxf(mx, sacc[j][1][15]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[j], mx * p.c);  // every tile has >= 1 valid key, so m_new is finite
+      float m_new = fmaxf(m_run[j], mx * p.c);  // unmasked: every tile has >= 1 valid key, so m_new is finite
+      if constexpr (MASKED) {
+        if (m_new == -INFINITY) m_new = 0.f;  // nothing visible to this query so far: P = exp2(-inf - 0) = 0, not NaN
+      }
       const bool moved = m_new != m_run[j];
       const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);  // first tile: exp2(-inf) = 0
       m_run[j] = m_new;
@@ -315,7 +336,10 @@ int launch_flash(const AttnArgs& a, hipStream_t stream) {
   constexpr int KP = 16 * DS + 8;
   const size_t lds = (size_t)2 * (KT * KP + KT * v_row_halfs(DF)) * sizeof(f16);  // ping-pong K and V images
   dim3 grid((a.Lq + 127) / 128, a.heads, a.batch);
-  hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5)>), grid, dim3(256), lds, stream, a);
+  if (a.kvalid || a.causal)
+    hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), true>), grid, dim3(256), lds, stream, a);
+  else
+    hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), false>), grid, dim3(256), lds, stream, a);
   return rcdm_check_launch();
 }
 
@@ -434,7 +458,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs p) {
 
 extern "C" {
 
-int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const void* V, void* out, void* stream_) {
+int rcdm_flash_attn_masked(const rcdm_attn_desc* d, const void* Q, const void* K, const void* V,
+                           const unsigned char* key_valid, int32_t causal, void* out, void* stream_) {
   if (!d || !Q || !K || !V || !out) return RCDM_EINVAL;
   if (d->batch <= 0 || d->heads <= 0 || d->Lq <= 0 || d->Lk <= 0 || d->d <= 0) return RCDM_EINVAL;
   if ((d->d & 7) || d->d > 160) return RCDM_ESHAPE;
@@ -446,6 +471,8 @@ int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const
   a.batch = d->batch; a.heads = d->heads; a.Lq = d->Lq; a.Lk = d->Lk; a.d = d->d; a.dch = d->d / 8;
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
   a.c = d->scale * 1.4426950408889634f;
+  a.kvalid = key_valid;
+  a.causal = causal ? 1 : 0;
   hipStream_t stream = (hipStream_t)stream_;
   const int ds = (d->d + 15) / 16;
   if (ds <= 1) return launch_flash<1>(a, stream);
@@ -453,6 +480,10 @@ int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const
   if (ds <= 3) return launch_flash<3>(a, stream);
   if (ds <= 5) return launch_flash<5>(a, stream);
   return launch_flash<10>(a, stream);
+}
+
+int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const void* V, void* out, void* stream_) {
+  return rcdm_flash_attn_masked(d, Q, K, V, nullptr, 0, out, stream_);
 }
 
 int rcdm_temporal_attn(const rcdm_temporal_attn_desc* d, const void* qkv, void* out, void* stream_) {

@@ -88,6 +88,10 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n,
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += rv[e];
   }
+  if (p.epi & RCDM_EPI_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+  }
   if (p.epi & RCDM_EPI_RESIDUAL) {
     Pack16 r;
     r.u = *(const uint4*)(p.res + (size_t)m * p.ldr + oc);
@@ -435,6 +439,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
                 for (int e = 0; e < 8; ++e) v[e] += rv[e];
               }
               Pack16 o;
+              if (p.epi & RCDM_EPI_GELU) {  // Linear -> GELU (exact erf form): after bias / row vector, before residual
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e] + bb[e]) - bb[e];
+              }
 #pragma unroll
               for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + bb[e] + (float)resv[WHOLE ? ps : 0][it].e[e]) * p.out_scale);
               *(uint4*)(p.out + (size_t)m * p.ldc + pn) = o.u;
@@ -588,6 +596,7 @@ int check_common(const IgemmArgs& a) {
   if ((a.epi & RCDM_EPI_ROWVEC) && (!a.rowvec || a.rows_per_sample <= 0 || (a.ldt & 3))) return RCDM_EINVAL;
   if ((a.epi & RCDM_EPI_RESIDUAL) && (!a.res || (a.ldr & 7))) return RCDM_EINVAL;
   if ((a.epi & RCDM_EPI_GEGLU) && (a.N % 64)) return RCDM_ESHAPE;
+  if ((a.epi & RCDM_EPI_GEGLU) && (a.epi & RCDM_EPI_GELU)) return RCDM_EINVAL;
   // buffer-load offsets are 32-bit with 0x80000000 reserved as "out of range"
   const size_t in_rows = (a.Ktot == a.Cin) ? (size_t)a.M : (size_t)(a.M / (a.Ho * a.Wo)) * a.Hi * a.Wi;
   if (in_rows * (size_t)a.lda * 2 >= 0x7FFFFFFFull || (size_t)a.N * a.Ktot * 2 >= 0x7FFFFFFFull) return RCDM_ESHAPE;

@@ -9,7 +9,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RCDM_LIB") or os.path.join(_HERE, "lib", "librcdm_hip.so")  # RCDM_LIB: kernel experiments
 
-EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
+EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU, EPI_GELU = 1, 2, 4, 8, 16
 
 _ERR = {-1: "RCDM_EINVAL", -2: "RCDM_ESHAPE", -3: "RCDM_ELAUNCH", -4: "RCDM_EWORKSPACE"}
 
@@ -72,6 +72,7 @@ SYMBOLS = {
     "rcdm_groupnorm_silu": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_layernorm": (C.c_int, [C.POINTER(LayerNormDesc), _P, _P, _P, _P, _P, _P]),
     "rcdm_flash_attn": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
+    "rcdm_flash_attn_masked": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _I, _P, _P]),
     "rcdm_temporal_attn": (C.c_int, [C.POINTER(TemporalAttnDesc), _P, _P, _P]),
     "rcdm_timestep_embed": (C.c_int, [_P, _I, _I, _P, _P]),
     "rcdm_small_linear": (C.c_int, [_P, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
@@ -175,6 +176,11 @@ def layernorm(desc, x, gamma, beta, pe, y, stream=None):
 def flash_attn(desc, q, k, v, out, stream=None):
     _check(load().rcdm_flash_attn(C.byref(desc), q, k, v, out,
                                   stream_ptr() if stream is None else stream), "rcdm_flash_attn")
+
+
+def flash_attn_masked(desc, q, k, v, key_valid, causal, out, stream=None):
+    _check(load().rcdm_flash_attn_masked(C.byref(desc), q, k, v, key_valid, int(causal), out,
+                                         stream_ptr() if stream is None else stream), "rcdm_flash_attn_masked")
 
 
 def temporal_attn(desc, qkv, out, stream=None):

@@ -255,6 +255,56 @@ def test_flash_attn(hiplib, batch, heads, Lq, Lk, d):
     close(out.reshape(batch, Lq, C), ref)
 
 
+@pytest.mark.parametrize("batch,heads,L,d,causal,pad", [
+    (2, 4, 97, 64, True, True),      # the stage-1 prior's shape: 91 text + 6 extra tokens, causal + text padding
+    (2, 4, 97, 64, True, False),
+    (3, 2, 150, 40, False, True),    # padding only, three key tiles
+    (1, 2, 64, 160, True, True),     # un-pipelined (d > 80) variant
+])
+def test_flash_attn_masked(hiplib, batch, heads, L, d, causal, pad):
+    """rcdm_flash_attn_masked vs the reference's ADDITIVE mask (0 / -10000, myprior_transformer.py:389-393)."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(5 + L + d)
+    C = heads * d
+    q, k, v = (h16(torch.randn(batch, L, C, generator=g)) for _ in range(3))
+    valid = torch.ones(batch, L, dtype=torch.uint8)
+    if pad:
+        for b in range(batch):
+            valid[b, 20 + 7 * b:L - 6] = 0          # padded text tokens; the trailing extra tokens stay visible
+    add = (1.0 - valid.float())[:, None, :] * -10000.0
+    if causal:
+        add = add + torch.full((L, L), -10000.0).triu_(1)[None]
+    else:
+        add = add.expand(batch, L, L)
+    ref = O.attention_core(q, k, v, heads, mask=add)
+    qd, kd, vd = (t.reshape(-1, C).half().to(DEV) for t in (q, k, v))
+    vm = valid.to(DEV)
+    out = torch.empty(batch * L, C, dtype=torch.float16, device=DEV)
+    desc = hip.AttnDesc(batch, heads, L, L, d, C, C, C, C, d ** -0.5)
+    hip.flash_attn_masked(desc, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), vm.data_ptr() if pad else 0, causal,
+                          out.data_ptr())
+    torch.cuda.synchronize()
+    close(out.reshape(batch, L, C), ref)
+
+
+def test_gemm_gelu(hiplib):
+    """Linear -> exact GELU epilogue (the prior's FeedForward(activation_fn="gelu")), plain and split-K paths."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(23)
+    for M, N, K, split in [(970, 512, 256, 1), (130, 72, 200, 3)]:
+        A = h16(torch.randn(M, K, generator=g))
+        W = h16(torch.randn(N, K, generator=g) * K ** -0.5)
+        bias = torch.randn(N, generator=g)
+        ref = F.gelu(F.linear(A, W, bias))
+        Ad, Wd, bd = A.half().to(DEV), W.half().to(DEV), bias.to(DEV)
+        out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        dsc = hip.GemmDesc(M, N, K, K, N, 0, hip.EPI_BIAS | hip.EPI_GELU, 1, 0, 1.0, split)
+        w = ws(hip.gemm_workspace_bytes(dsc))
+        hip.gemm(dsc, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), 0, 0, out.data_ptr(), w.data_ptr(), w.numel())
+        torch.cuda.synchronize()
+        close(out, ref)
+
+
 def test_flash_attn_forced_rescale(hiplib):
     """A key in a LATE tile that dominates one query's scores forces the online-softmax rescale branch."""
     from rcdms_amd import hip
