@@ -2,7 +2,7 @@
 REFERENCE's own model classes (imported from /root/reference through oracle/ref_scaffold.py) on CPU fp32
 with procedural name-seeded weights (rcdms_amd/synth.py).  Run in the build container only:
 
-    python -m oracle.make_golden [--full] [--only blocks|tiny|ctx|full]   # --full adds the full-width UNet (32x32, 64x64)
+    python -m oracle.make_golden [--full] [--only blocks|tiny|ctx|prior|full]   # --full adds the full-width UNet (32x32, 64x64)
 
 What is stored: small inputs and the reference outputs (fp32 .npz), plus a digest of the reference's
 state-dict key/shape list so the mirrored classes are checked to have the identical 1286-key layout.
@@ -145,6 +145,39 @@ def ctx_stacks():
         save(name, out=out, seed=seed, k=k, lv=lv, vis_dim=vis_dim, key_digest=digest)
 
 
+PRIOR_CASES = {  # name: (num_layers, heads, head_dim, embedding_dim, seed)
+    "prior_tiny": (2, 4, 64, 128, 401),
+    "prior_full": (20, 32, 64, 1280, 402),   # the Kandinsky-2.2 prior shape the driver loads (2.85 G parameters)
+}
+
+
+def prior_inputs(name, B, E, T, seed):
+    """Inputs of MyPriorTransformer.forward for one CFG batch of a 5-frame story (B = 2 x 5), regenerated by the tests."""
+    t = lambda k, shape: synth.normal_tensor(f"{name}.{k}", shape, seed)
+    am = torch.ones(B, T)
+    for b in range(B):
+        am[b, 12 + 3 * b:] = 0.0          # text padding: tokens past the caption length are masked
+    return dict(hidden_states=t("hidden_states", (B, E)), proj_embedding=t("proj_embedding", (B, E)),
+                encoder_hidden_states=t("encoder_hidden_states", (B, T, E)), proj_embedding1=t("proj_embedding1", (B, E)),
+                mask_label=t("mask_label", (B, E)), attention_mask=am)
+
+
+@torch.no_grad()
+def prior(which):
+    """Stage-1 prior transformer: outputs of the reference class on procedural weights."""
+    for name in which:
+        layers, heads, hd, E, seed = PRIOR_CASES[name]
+        t0 = time.time()
+        m = ref_scaffold.build_reference_prior(num_layers=layers, heads=heads, head_dim=hd, embedding_dim=E)
+        digest = load_procedural(m, seed)
+        x = prior_inputs(name, 10, E, 91, seed)
+        y = m(x["hidden_states"], torch.tensor(481), x["proj_embedding"], x["encoder_hidden_states"],
+              x["proj_embedding1"], x["mask_label"], attention_mask=x["attention_mask"]).predicted_image_embedding
+        print("  reference prior %s: %.1f s" % (name, time.time() - t0))
+        save(name, y=y, t=np.int64(481), seed=seed, key_digest=digest,
+             cfg=np.array([layers, heads, hd, E], dtype=np.int64))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -157,5 +190,7 @@ if __name__ == "__main__":
         print("tiny UNet"); tiny_unet()
     if a.only in ("", "ctx"):
         print("context stacks"); ctx_stacks()
+    if a.only in ("", "prior"):
+        print("prior transformer"); prior(["prior_tiny"] + (["prior_full"] if a.full else []))
     if a.full or a.only == "full":
         print("full UNet"); full_unet()

@@ -98,11 +98,12 @@ class Timesteps(nn.Module):
 
 
 class TimestepEmbedding(nn.Module):
-    def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
+    def __init__(self, in_channels, time_embed_dim, act_fn="silu", out_dim=None):
         super().__init__()
+        assert act_fn == "silu"
         self.linear_1 = nn.Linear(in_channels, time_embed_dim)
         self.act = nn.SiLU()
-        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+        self.linear_2 = nn.Linear(time_embed_dim, out_dim or time_embed_dim)
 
     def forward(self, sample):
         return self.linear_2(self.act(self.linear_1(sample)))
@@ -118,12 +119,22 @@ class GEGLU(nn.Module):
         return x * F.gelu(gate)
 
 
+class GELU(nn.Module):  # diffusers 0.24.0 models.activations.GELU(dim_in, dim_out, approximate="none")
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out)
+
+    def forward(self, x):
+        return F.gelu(self.proj(x))
+
+
 class FeedForward(nn.Module):
     def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="geglu", final_dropout=False):
         super().__init__()
         inner = int(dim * mult)
-        assert activation_fn == "geglu"
-        self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out or dim)])
+        assert activation_fn in ("geglu", "gelu")
+        act = GEGLU(dim, inner) if activation_fn == "geglu" else GELU(dim, inner)
+        self.net = nn.ModuleList([act, nn.Dropout(dropout), nn.Linear(inner, dim_out or dim)])
 
     def forward(self, x):
         for m in self.net:
@@ -157,7 +168,14 @@ def install():
     emb = _mod("diffusers.models.embeddings", Timesteps=Timesteps, TimestepEmbedding=TimestepEmbedding)
     att = _mod("diffusers.models.attention", FeedForward=FeedForward, AdaLayerNorm=AdaLayerNorm)
     models = _mod("diffusers.models", embeddings=emb, attention=att)
-    d = _mod("diffusers", ModelMixin=ModelMixin, utils=utils, configuration_utils=cfgu, models=models)
+    # extra names src/models/myprior_transformer.py imports (stage-1 prior); none carries arithmetic
+    loaders = _mod("diffusers.loaders", UNet2DConditionLoadersMixin=type("UNet2DConditionLoadersMixin", (), {}))
+    ap = _mod("diffusers.models.attention_processor",
+              ADDED_KV_ATTENTION_PROCESSORS=(), CROSS_ATTENTION_PROCESSORS=(), AttentionProcessor=object,
+              AttnAddedKVProcessor=type("AttnAddedKVProcessor", (), {}), AttnProcessor=type("AttnProcessor", (), {}))
+    mu = _mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
+    models.attention_processor, models.modeling_utils = ap, mu
+    d = _mod("diffusers", ModelMixin=ModelMixin, utils=utils, configuration_utils=cfgu, models=models, loaders=loaders)
     d._rcdm_stub = True
 
 
@@ -261,3 +279,24 @@ def load_reference_context_stacks():
             else:
                 sys.modules[k] = v
     return m.fine_stack, m.semantic_stack
+
+
+PRIOR_MOTION_KWARGS = dict(num_attention_heads=8, num_transformer_block=1,
+                           attention_block_types=["Temporal_Self", "Temporal_Self"], temporal_position_encoding=True,
+                           temporal_position_encoding_max_len=5, temporal_attention_dim_div=1)
+
+
+def build_reference_prior(num_layers=20, heads=32, head_dim=64, embedding_dim=1280, num_embeddings=91,
+                          additional_embeddings=6):
+    """The reference's MyPriorTransformer (src/models/myprior_transformer.py) as stage1_batchtest_rcdms_model.py:99
+    builds it: the Kandinsky-2.2 prior config with num_embeddings / additional_embeddings overridden
+    (myprior_transformer.py:428-429) and the testing.yaml motion-module kwargs.  Smaller sizes for fixtures."""
+    load_reference_models()
+    mod = importlib.import_module("refsrc.models.myprior_transformer")
+    cfg = dict(num_attention_heads=heads, attention_head_dim=head_dim, num_layers=num_layers,
+               embedding_dim=embedding_dim, num_embeddings=num_embeddings, additional_embeddings=additional_embeddings,
+               dropout=0.0, time_embed_act_fn="silu", norm_in_type=None, embedding_proj_norm_type=None,
+               encoder_hid_proj_type="linear", added_emb_type="prd")
+    return mod.MyPriorTransformer(**cfg, unet_use_cross_frame_attention=False, unet_use_temporal_attention=False,
+                                  use_motion_module=True, motion_module_type="Vanilla",
+                                  motion_module_kwargs=dict(PRIOR_MOTION_KWARGS)).eval()

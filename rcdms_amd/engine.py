@@ -99,7 +99,8 @@ class Plan:
 # ------------------------------------------------------------------------------------------------
 # single-kernel emitters
 
-def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geglu=False, scale=1.0, split_k=0):
+def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geglu=False, scale=1.0, split_k=0,
+              gelu=False):
     """out[M][N or N/2] = epi(A[M][K] W[N][K]^T); rowvec = (tensor, elem_offset, ldt, rows_per_sample)."""
     epi = 0
     if bias is not None:
@@ -110,6 +111,8 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
         epi |= hip.EPI_RESIDUAL
     if geglu:
         epi |= hip.EPI_GEGLU
+    if gelu:
+        epi |= hip.EPI_GELU
     d = hip.GemmDesc(A.M, N, K, A.ld, out.ld, residual.ld if residual is not None else 0, epi,
                      rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k)
     wsb = hip.gemm_workspace_bytes(d)
@@ -176,6 +179,17 @@ def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out):
     def op():
         hip.flash_attn(d, q.ptr, k.ptr, v.ptr, out.ptr)
     plan.add(op, f"flash_attn B={batch} H={heads} Lq={Lq} Lk={Lk} d={d_head}")
+    plan.n_launch += 1
+
+
+def emit_flash_attn_masked(plan, q, k, v, batch, heads, Lq, Lk, d_head, out, key_valid, causal):
+    """key_valid: uint8 tensor [batch][Lk] (or None); causal: bool — rcdm_flash_attn_masked."""
+    d = hip.AttnDesc(batch, heads, Lq, Lk, d_head, q.ld, k.ld, v.ld, out.ld, d_head ** -0.5)
+
+    def op():
+        hip.flash_attn_masked(d, q.ptr, k.ptr, v.ptr, key_valid.data_ptr() if key_valid is not None else 0, causal, out.ptr)
+    plan.add(op, f"flash_attn_masked B={batch} H={heads} L={Lq} d={d_head}")
+    plan.keep += [key_valid]
     plan.n_launch += 1
 
 
@@ -281,6 +295,8 @@ def pack_motion(pk, p, n_attn):
     b = p + "transformer_blocks.0."
     w = _NS(C=C)
     w.gn_g, w.gn_b = pk.vec(p + "norm.weight"), pk.vec(p + "norm.bias")
+    if pk.has(p + "prior_norm.weight"):  # LayerNorm used instead of the GroupNorm when prior_state (stage 1)
+        w.prior_g, w.prior_b = pk.vec(p + "prior_norm.weight"), pk.vec(p + "prior_norm.bias")
     w.proj_in, w.proj_in_b = pk.mat_f16(p + "proj_in.weight"), pk.vec(p + "proj_in.bias")
     w.proj_out, w.proj_out_b = pk.mat_f16(p + "proj_out.weight"), pk.vec(p + "proj_out.bias")
     w.attn = []
@@ -367,13 +383,17 @@ def emit_ctx_kv(plan, w, ctx16, ctx_kv):
     emit_gemm(plan, ctx16, w.kv2, 2 * w.C, w.ctx_dim, ctx_kv)
 
 
-def emit_motion(plan, w, x, geo, heads, out, groups=32):
+def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
     """VanillaTemporalModule -> TemporalTransformer3DModel.forward -> TemporalTransformerBlock.forward
-    (src/models/motion_module.py:87-93,147-182,234-246)."""
+    (src/models/motion_module.py:87-93,147-182,234-246).  prior_state (stage-1 prior, :150-153,172-174): the rows are
+    (b f) x n tokens (geo.hw = n), the leading norm is the LayerNorm `prior_norm` instead of the per-frame GroupNorm."""
     g, C = geo, w.C
     d_head = C // heads
     a = plan.rows("norm", g.M, C)
-    emit_groupnorm(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, False, a, groups)
+    if prior_state:
+        emit_layernorm(plan, x, w.prior_g, w.prior_b, a)
+    else:
+        emit_groupnorm(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, False, a, groups)
     tok = plan.rows("tok", g.M, C)
     emit_gemm(plan, a, w.proj_in, C, C, tok, bias=w.proj_in_b)
     for at in w.attn:

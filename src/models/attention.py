@@ -23,15 +23,25 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
 
+class GELU(nn.Module):
+    """diffusers GELU(dim_in, dim_out): proj -> exact gelu.  Parameter holder (the gelu is a GEMM epilogue)."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out)
+
+
 class FeedForward(nn.Module):
-    """diffusers FeedForward(dim, activation_fn="geglu"): net = [GEGLU(dim, 4 dim), Dropout, Linear(4 dim, dim)]."""
+    """diffusers FeedForward(dim, activation_fn): net = [GEGLU | GELU (dim, 4 dim), Dropout, Linear(4 dim, dim)];
+    "geglu" in the stage-2 UNet and every motion module, "gelu" in the stage-1 prior's transformer blocks."""
 
     def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="geglu"):
         super().__init__()
-        if activation_fn != "geglu":
-            raise NotImplementedError("FeedForward: only geglu (what the stage-2 UNet uses)")
+        if activation_fn not in ("geglu", "gelu"):
+            raise NotImplementedError("FeedForward: geglu (stage-2 UNet, motion modules) or gelu (stage-1 prior)")
         inner = int(dim * mult)
-        self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out or dim)])
+        act = GEGLU(dim, inner) if activation_fn == "geglu" else GELU(dim, inner)
+        self.net = nn.ModuleList([act, nn.Dropout(dropout), nn.Linear(inner, dim_out or dim)])
 
 
 class CrossAttention(nn.Module):
@@ -41,17 +51,17 @@ class CrossAttention(nn.Module):
                  dropout: float = 0.0, bias=False, upcast_attention: bool = False, upcast_softmax: bool = False,
                  added_kv_proj_dim: Optional[int] = None, norm_num_groups: Optional[int] = None):
         super().__init__()
-        if added_kv_proj_dim is not None or norm_num_groups is not None or bias:
-            raise NotImplementedError("CrossAttention: added_kv / group_norm / qkv bias are unused by stage 2")
+        if added_kv_proj_dim is not None or norm_num_groups is not None:
+            raise NotImplementedError("CrossAttention: added_kv / group_norm are unused by the reference's configs")
         inner = dim_head * heads
         self.heads, self.scale = heads, dim_head ** -0.5
         self.sliceable_head_dim, self._slice_size = heads, None
         self.upcast_attention, self.upcast_softmax = upcast_attention, upcast_softmax
         self._use_memory_efficient_attention_xformers = False
         kv_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
-        self.to_q = nn.Linear(query_dim, inner, bias=False)
-        self.to_k = nn.Linear(kv_dim, inner, bias=False)
-        self.to_v = nn.Linear(kv_dim, inner, bias=False)
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)   # bias only in the stage-1 prior (attention_bias=True)
+        self.to_k = nn.Linear(kv_dim, inner, bias=bias)
+        self.to_v = nn.Linear(kv_dim, inner, bias=bias)
         self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
 
     def set_attention_slice(self, slice_size):
@@ -73,14 +83,16 @@ class BasicTransformerBlock(nn.Module):
         super().__init__()
         assert unet_use_cross_frame_attention is not None and unet_use_temporal_attention is not None
         if unet_use_cross_frame_attention or unet_use_temporal_attention or num_embeds_ada_norm is not None \
-                or only_cross_attention or cross_attention_dim is None:
+                or only_cross_attention:
             raise NotImplementedError("BasicTransformerBlock: configuration not used by configs/testing.yaml")
         mk = dict(heads=num_attention_heads, dim_head=attention_head_dim, dropout=dropout, bias=attention_bias,
                   upcast_attention=upcast_attention)
         self.attn1 = CrossAttention(query_dim=dim, **mk)
         self.norm1 = nn.LayerNorm(dim)
-        self.attn2 = CrossAttention(query_dim=dim, cross_attention_dim=cross_attention_dim, **mk)
-        self.norm2 = nn.LayerNorm(dim)
+        # no cross-attention in the stage-1 prior's blocks (attention.py:417-433: attn2 / norm2 are None)
+        self.attn2 = CrossAttention(query_dim=dim, cross_attention_dim=cross_attention_dim, **mk) \
+            if cross_attention_dim is not None else None
+        self.norm2 = nn.LayerNorm(dim) if cross_attention_dim is not None else None
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
         self.norm3 = nn.LayerNorm(dim)
 

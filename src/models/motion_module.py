@@ -103,8 +103,8 @@ class VanillaTemporalModule(nn.Module):
                  temporal_position_encoding=False, temporal_position_encoding_max_len=24,
                  temporal_attention_dim_div=1, zero_initialize=True, prior_state=False):
         super().__init__()
-        if prior_state or temporal_attention_dim_div != 1:
-            raise NotImplementedError("VanillaTemporalModule: stage-2 form only (prior_state False, dim_div 1)")
+        if temporal_attention_dim_div != 1:
+            raise NotImplementedError("VanillaTemporalModule: temporal_attention_dim_div 1 only (configs/testing.yaml)")
         self.prior_state = prior_state
         self.temporal_transformer = TemporalTransformer3DModel(
             in_channels=in_channels, num_attention_heads=num_attention_heads,
@@ -116,6 +116,8 @@ class VanillaTemporalModule(nn.Module):
             zero_module(self.temporal_transformer.proj_out)
 
     def forward(self, input_tensor, temb=None, encoder_hidden_states=None, attention_mask=None, anchor_frame_idx=None):
+        if self.prior_state:
+            raise NotImplementedError("prior_state motion modules run fused inside MyPriorTransformer on the HIP path")
         tt = self.temporal_transformer
         return engine.run_block("motion", self.state_dict(), input_tensor, heads=tt.num_attention_heads,
                                 n_attn=tt.n_attn, groups=tt.norm_num_groups)

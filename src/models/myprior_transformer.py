@@ -1,0 +1,141 @@
+"""Mirror of the reference's src/models/myprior_transformer.py interface: `MyPriorTransformer` (:38-448), the stage-1
+frame-prior transformer (a Kandinsky-2.2 PriorTransformer fork with a motion module after every block).  Parameter
+holder with the reference's constructor and state-dict keys; forward() runs on the HIP path (rcdms_amd/prior.py)."""
+import json
+import os
+from dataclasses import dataclass
+from itertools import chain
+from typing import Optional, Union
+
+import torch
+from torch import nn
+
+from rcdms_amd import hip
+from rcdms_amd.prior import PriorProgram
+from .attention import BasicTransformerBlock
+from .motion_module import get_motion_module
+from .unet import TimestepEmbedding, Timesteps
+
+
+@dataclass
+class PriorTransformerOutput:
+    predicted_image_embedding: torch.Tensor
+
+
+class _Config(dict):
+    __getattr__ = dict.__getitem__
+
+
+class MyPriorTransformer(nn.Module):
+    def __init__(self, num_attention_heads: int = 32, attention_head_dim: int = 64, num_layers: int = 20,
+                 embedding_dim: int = 768, num_embeddings=77, additional_embeddings=4, dropout: float = 0.0,
+                 time_embed_act_fn: str = "silu", norm_in_type: Optional[str] = None,
+                 embedding_proj_norm_type: Optional[str] = None, encoder_hid_proj_type: Optional[str] = "linear",
+                 added_emb_type: Optional[str] = "prd", time_embed_dim: Optional[int] = None,
+                 embedding_proj_dim: Optional[int] = None, clip_embed_dim: Optional[int] = None,
+                 unet_use_cross_frame_attention=None, unet_use_temporal_attention=None, use_motion_module=None,
+                 motion_module_type=None, motion_module_kwargs=None):
+        super().__init__()
+        if norm_in_type is not None or embedding_proj_norm_type is not None or encoder_hid_proj_type != "linear" \
+                or added_emb_type != "prd" or time_embed_act_fn != "silu" or not use_motion_module \
+                or time_embed_dim is not None:
+            raise NotImplementedError("MyPriorTransformer: only the configuration stage1_batchtest_rcdms_model.py loads "
+                                      "(Kandinsky-2.2 prior config + configs/testing.yaml motion module)")
+        inner = num_attention_heads * attention_head_dim
+        embedding_proj_dim = embedding_proj_dim or embedding_dim
+        clip_embed_dim = clip_embed_dim or embedding_dim
+        self.config = _Config(num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
+                              num_layers=num_layers, embedding_dim=embedding_dim, num_embeddings=num_embeddings,
+                              additional_embeddings=additional_embeddings, clip_embed_dim=clip_embed_dim,
+                              motion_module_kwargs=dict(motion_module_kwargs or {}))
+        self.num_attention_heads, self.attention_head_dim = num_attention_heads, attention_head_dim
+        self.additional_embeddings = additional_embeddings
+        self.time_proj = Timesteps(inner, True, 0)
+        self.time_embedding = TimestepEmbedding(inner, inner)
+        self.proj_in = nn.Linear(embedding_dim, inner)
+        self.embedding_proj_norm = None
+        self.embedding_proj = nn.Linear(embedding_proj_dim, inner)
+        self.embedding_proj1 = nn.Linear(embedding_proj_dim, inner)
+        self.embedding_proj2 = nn.Linear(embedding_proj_dim, inner)
+        self.encoder_hidden_states_proj = nn.Linear(embedding_dim, inner)
+        self.encoder_hidden_states_proj1 = nn.Linear(1664, inner)   # present in the checkpoint, unused by forward
+        self.positional_embedding = nn.Parameter(torch.zeros(1, num_embeddings + additional_embeddings, inner))
+        self.prd_embedding = nn.Parameter(torch.zeros(1, 1, inner))
+        self.transformer_blocks = nn.ModuleList(list(chain(*[(
+            BasicTransformerBlock(inner, num_attention_heads, attention_head_dim, dropout=dropout, activation_fn="gelu",
+                                  attention_bias=True, unet_use_cross_frame_attention=unet_use_cross_frame_attention,
+                                  unet_use_temporal_attention=unet_use_temporal_attention),
+            get_motion_module(in_channels=inner, prior_state=True, motion_module_type=motion_module_type,
+                              motion_module_kwargs=motion_module_kwargs)) for _ in range(num_layers)])))
+        self.norm_in = None
+        self.norm_out = nn.LayerNorm(inner)
+        self.proj_to_clip_embeddings = nn.Linear(inner, clip_embed_dim)
+        self.clip_mean = torch.tensor(-0.016)
+        self.clip_std = torch.tensor(0.415)
+        self._prog = None
+
+    @property
+    def device(self):
+        return self.proj_in.weight.device
+
+    @property
+    def dtype(self):
+        return self.proj_in.weight.dtype
+
+    def _program(self, B, T):
+        key = (B, T, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        if self._prog is None or self._prog[0] != key:
+            self._prog = (key, PriorProgram(dict(self.config), self.state_dict(), B, T, self.device))
+        return self._prog[1]
+
+    @torch.no_grad()
+    def forward(self, hidden_states, timestep: Union[torch.Tensor, float, int], proj_embedding,
+                encoder_hidden_states=None, proj_embedding1=None, mask_label=None, attention_mask=None,
+                return_dict: bool = True):
+        if self.device.type != "cuda":
+            raise hip.RcdmError(f"MyPriorTransformer runs on the HIP path only (module is on {self.device}); "
+                                "there is no CPU fallback")
+        if encoder_hidden_states is None:
+            raise ValueError("`encoder_hidden_states_proj` requires `encoder_hidden_states` to be set")
+        B, T = hidden_states.shape[0], encoder_hidden_states.shape[1]
+        prog = self._program(B, T)
+        ctx = (proj_embedding, encoder_hidden_states, proj_embedding1, mask_label, attention_mask)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else None for t in ctx)
+        if prog.ctx_key != key:
+            prog.set_context(*ctx)
+            prog.ctx_key = key
+        out = prog.forward(hidden_states, timestep).to(hidden_states.dtype)
+        return PriorTransformerOutput(predicted_image_embedding=out) if return_dict else (out,)
+
+    def post_process_latents(self, prior_latents):
+        return (prior_latents * self.clip_std) + self.clip_mean
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        import inspect
+        accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        merged = {k: v for k, v in dict(config).items() if k in accepted}
+        merged.update({k: v for k, v in kwargs.items() if k in accepted})
+        return cls(**merged)
+
+    @classmethod
+    def from_pretrained_2d(cls, pretrained_model_path, subfolder=None, unet_additional_kwargs=None):
+        """myprior_transformer.py:416-448: config.json of the Kandinsky prior with num_embeddings / additional_embeddings
+        forced to 91 / 6, weights loaded non-strictly minus `positional_embedding`."""
+        if subfolder is not None:
+            pretrained_model_path = os.path.join(pretrained_model_path, subfolder)
+        config_file = os.path.join(pretrained_model_path, "config.json")
+        if not os.path.isfile(config_file):
+            raise RuntimeError(f"{config_file} does not exist")
+        with open(config_file) as f:
+            config = json.load(f)
+        config["num_embeddings"], config["additional_embeddings"] = 91, 6
+        model = cls.from_config(config, **(unet_additional_kwargs or {}))
+        model_file = os.path.join(pretrained_model_path, "diffusion_pytorch_model.bin")
+        if not os.path.isfile(model_file):
+            raise RuntimeError(f"{model_file} does not exist")
+        state_dict = torch.load(model_file, map_location="cpu")
+        match = {k: v for k, v in state_dict.items() if not k.startswith("positional_embedding")}
+        missing, unexpected = model.load_state_dict(match, strict=False)
+        print(f"### missing keys: {len(missing)}; \n### unexpected keys: {len(unexpected)};")
+        return model
