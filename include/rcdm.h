@@ -223,6 +223,19 @@ int rcdm_rows_to_ncfhw(const void* rows, int32_t ld, int32_t b, int32_t C, int32
 int rcdm_cfg_ddim_step(const void* eps, int32_t ld, float* latents, int32_t S, int32_t reps,
                        int32_t frames, int32_t H, int32_t W, float guidance_scale, const float* coef,
                        const int32_t* step_counter, void* stream);
+/* Stage-1 prior, per step of prior_pipeline.py:311-344.
+ * rcdm_prior_assemble: tok[(b, l)] (f16, B*L rows of C) <- base rows, except l == time_row <- temb (one fp32 row of C);
+ *   x16[b] (f16, E) <- latents[b % n_lat] (fp32): the `torch.cat([latents] * 2)` of :314 and the sequence concat of
+ *   myprior_transformer.py:363-387 without re-projecting what does not change between steps.
+ * rcdm_cfg_unclip_step: x0 = clamp(u + s (c - u), +-clip_range) with u / c = rows r / n + r of pred (f16, ld);
+ *   latents[r] = coef[*step][0] x0 + coef[*step][1] latents[r] + coef[*step][2] noise[*step][r]  — the CFG combine
+ *   (:328-333) fused with diffusers 0.24.0 UnCLIPScheduler.step for prediction_type "sample" / "fixed_small_log";
+ *   coef fp32 [n_steps][3]; noise fp32 [n_steps][n][E] or NULL; clip_range <= 0 disables the clamp. */
+int rcdm_prior_assemble(const void* base, const float* temb, const float* latents, int32_t n_lat, void* tok, void* x16,
+                        int32_t B, int32_t L, int32_t C, int32_t E, int32_t time_row, void* stream);
+int rcdm_cfg_unclip_step(const void* pred, int32_t ld, float* latents, int32_t n, int32_t reps, int32_t E,
+                         float guidance_scale, float clip_range, const float* coef, const float* noise,
+                         const int32_t* step_counter, void* stream);
 /* t_out[0..rows) = timesteps[*step_counter] (fp32) — feeds rcdm_timestep_embed inside a graph */
 int rcdm_load_timestep(const float* timesteps, const int32_t* step_counter, float* t_out,
                        int32_t rows, void* stream);

@@ -81,3 +81,25 @@ def prior_forward(sd, cfg, hidden_states, timestep, proj_embedding, encoder_hidd
         seq = prior_motion_module(sd, f"transformer_blocks.{2 * i + 1}.", seq, cfg["motion_heads"], cfg["motion_attn"])
     seq = O.layer_norm(sd, "norm_out.", seq)[:, -1]                                     # :404-406
     return F.linear(seq, sd["proj_to_clip_embeddings.weight"], sd["proj_to_clip_embeddings.bias"])
+
+
+def prior_denoise_loop(sd, cfg, scheduler, latents, proj_embedding, encoder_hidden_states, proj_embedding1, mask_label,
+                       attention_mask, num_steps, guidance_scale, noise):
+    """The sampling loop of Seq_Inpaint_Prior_Pipeline.__call__ (src/pipelines/prior_pipeline.py:293-344) with the
+    scheduler's per-step noise supplied (`noise` (T, n, E)) instead of drawn: duplicate the latents for CFG (:314),
+    prior forward (:316-325), CFG combine (:327-333), scheduler.step with prev_timestep = the next timestep (:335-344).
+    `scheduler`: rcdms_amd.scheduler.UnCLIPScheduler (diffusers arithmetic restated; parity unpinned)."""
+    scheduler.set_timesteps(num_steps)
+    ts = scheduler.timesteps.tolist()
+    cfg_on = guidance_scale > 1.0
+    lat = latents.float() * scheduler.init_noise_sigma
+    for i, t in enumerate(ts):
+        x = torch.cat([lat] * 2) if cfg_on else lat
+        pred = prior_forward(sd, cfg, x, t, proj_embedding, encoder_hidden_states, proj_embedding1, mask_label,
+                             attention_mask)
+        if cfg_on:
+            u, c = pred.chunk(2)
+            pred = u + guidance_scale * (c - u)
+        prev_t = ts[i + 1] if i + 1 < len(ts) else None
+        lat = scheduler.step(pred, t, lat, prev_timestep=prev_t, noise=noise[i]).prev_sample
+    return lat

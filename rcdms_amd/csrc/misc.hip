@@ -138,6 +138,59 @@ __global__ void cfg_ddim_kernel(const f16* __restrict__ eps, int ld, float* lat,
   lat[idx] = k[2] * x0 + k[3] * e;
 }
 
+// Stage-1 prior, per-step sequence assembly.  tok rows (b, l) <- the step-independent rows of `base`, except row
+// l == time_row of every sample, which takes the time embedding (one fp32 row, shared by the batch); x16 rows <-
+// the noisy embeddings in f16, sample b reading latent row b % n_lat (classifier-free guidance feeds the same 5
+// latents to both halves: torch.cat([latents] * 2), prior_pipeline.py:314).
+__global__ void prior_assemble_kernel(const f16* __restrict__ base, const float* __restrict__ temb,
+                                      const float* __restrict__ lat, int n_lat, f16* __restrict__ tok,
+                                      f16* __restrict__ x16, int B, int L, int C, int E, int time_row) {
+  const size_t chunks = (size_t)B * L * (C / 8);
+  const size_t nx = (size_t)B * E;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks + nx; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < chunks) {
+      const int c8 = (int)(i % (C / 8));
+      const size_t row = i / (C / 8);
+      const int l = (int)(row % L);
+      Pack16 v;
+      if (l == time_row) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.e[e] = (f16)temb[c8 * 8 + e];
+      } else {
+        v.u = *(const uint4*)(base + row * C + c8 * 8);
+      }
+      *(uint4*)(tok + row * C + c8 * 8) = v.u;
+    } else {
+      const size_t j = i - chunks;
+      const int b = (int)(j / E), e = (int)(j - (size_t)b * E);
+      x16[j] = (f16)lat[(size_t)(b % n_lat) * E + e];
+    }
+  }
+}
+
+// Stage-1 prior, CFG combine + UnCLIPScheduler.step (prediction_type "sample", variance_type "fixed_small_log"),
+// prior_pipeline.py:328-344 + diffusers 0.24.0 UnCLIPScheduler.step: x0 = clamp(u + s (c - u), +-clip);
+// lat = k0 x0 + k1 lat + k2 noise, with (k0, k1, k2) = coef[*step] (k2 = 0 on the last step).
+__global__ void cfg_unclip_kernel(const f16* __restrict__ pred, int ld, float* lat, int n, int reps, int E, float gs,
+                                  float clip, const float* __restrict__ coef, const float* __restrict__ noise,
+                                  const int* __restrict__ step) {
+  const size_t total = (size_t)n * E;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int r = (int)(idx / E), e = (int)(idx - (size_t)r * E);
+  float x0 = (float)pred[(size_t)r * ld + e];
+  if (reps == 2) {
+    const float xc = (float)pred[(size_t)(n + r) * ld + e];
+    x0 = x0 + gs * (xc - x0);
+  }
+  if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
+  const int st = *step;
+  const float* k = coef + (size_t)st * 3;
+  float v = k[0] * x0 + k[1] * lat[idx];
+  if (noise) v += k[2] * noise[(size_t)st * total + idx];
+  lat[idx] = v;
+}
+
 __global__ void load_timestep_kernel(const float* __restrict__ ts, const int* __restrict__ step, float* t_out, int rows) {
   const int i = threadIdx.x;
   if (i < rows) t_out[i] = ts[*step];
@@ -237,6 +290,28 @@ int rcdm_cfg_ddim_step(const void* eps, int32_t ld, float* latents, int32_t S, i
   const size_t total = (size_t)S * 4 * frames * H * W;
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const f16*)eps, ld, latents, S, reps, frames, H, W, guidance_scale, coef, step_counter);
+  return rcdm_check_launch();
+}
+
+int rcdm_prior_assemble(const void* base, const float* temb, const float* latents, int32_t n_lat, void* tok, void* x16,
+                        int32_t B, int32_t L, int32_t C, int32_t E, int32_t time_row, void* stream) {
+  if (!base || !temb || !latents || !tok || !x16) return RCDM_EINVAL;
+  if (B <= 0 || L <= 0 || C <= 0 || E <= 0 || n_lat <= 0 || time_row < 0 || time_row >= L) return RCDM_EINVAL;
+  if (C & 7) return RCDM_ESHAPE;
+  const size_t n = (size_t)B * L * (C / 8) + (size_t)B * E;
+  hipLaunchKernelGGL(prior_assemble_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const f16*)base, temb,
+                     latents, n_lat, (f16*)tok, (f16*)x16, B, L, C, E, time_row);
+  return rcdm_check_launch();
+}
+
+int rcdm_cfg_unclip_step(const void* pred, int32_t ld, float* latents, int32_t n, int32_t reps, int32_t E,
+                         float guidance_scale, float clip_range, const float* coef, const float* noise,
+                         const int32_t* step_counter, void* stream) {
+  if (!pred || !latents || !coef || !step_counter) return RCDM_EINVAL;
+  if (n <= 0 || (reps != 1 && reps != 2) || E <= 0 || ld < E) return RCDM_EINVAL;
+  const size_t total = (size_t)n * E;
+  hipLaunchKernelGGL(cfg_unclip_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f16*)pred, ld, latents, n, reps, E, guidance_scale, clip_range, coef, noise, step_counter);
   return rcdm_check_launch();
 }
 

@@ -80,6 +80,8 @@ SYMBOLS = {
     "rcdm_ncfhw_to_rows": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "rcdm_rows_to_ncfhw": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "rcdm_cfg_ddim_step": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "rcdm_prior_assemble": (C.c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rcdm_cfg_unclip_step": (C.c_int, [_P, _I, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P]),
     "rcdm_load_timestep": (C.c_int, [_P, _P, _P, _I, _P]),
     "rcdm_advance_step": (C.c_int, [_P, _P]),
     "rcdm_pack_f16": (C.c_int, [_P, _P, _SZ, _P]),
@@ -196,6 +198,16 @@ def timestep_embed(t, rows, dim, out, stream=None):
 def small_linear(x, rows, K, W, bias, N, silu_in, silu_out, out, stream=None):
     _check(load().rcdm_small_linear(x, rows, K, W, bias, N, silu_in, silu_out, out,
                                     stream_ptr() if stream is None else stream), "rcdm_small_linear")
+
+
+def prior_assemble(base, temb, latents, n_lat, tok, x16, B, L, Cc, E, time_row, stream=None):
+    _check(load().rcdm_prior_assemble(base, temb, latents, n_lat, tok, x16, B, L, Cc, E, time_row,
+                                      stream_ptr() if stream is None else stream), "rcdm_prior_assemble")
+
+
+def cfg_unclip_step(pred, ld, latents, n, reps, E, guidance_scale, clip_range, coef, noise, step_counter, stream=None):
+    _check(load().rcdm_cfg_unclip_step(pred, ld, latents, n, reps, E, guidance_scale, clip_range, coef, noise,
+                                       step_counter, stream_ptr() if stream is None else stream), "rcdm_cfg_unclip_step")
 
 
 def assemble_input(lat, mask, masked, S, reps, frames, H, W, out, ld, c_pad, stream=None):

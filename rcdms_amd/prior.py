@@ -107,6 +107,7 @@ class PriorProgram:
         emit_layernorm(plan, last, ln_out[0], ln_out[1], fin)
         emit_gemm(plan, fin, self.w_clip, self.clip_dim, C, self.out16, bias=self.b_clip)
         plan.materialize()
+        self._d_in = hip.GemmDesc(B, C, self.E, self.E, L * C, 0, hip.EPI_BIAS, 1, 0, 1.0, 1)
         self.ctx_key = None
 
     # ---- per story ------------------------------------------------------------------------------------------------
@@ -143,39 +144,44 @@ class PriorProgram:
         self.ctx_key = True
 
     # ---- per step --------------------------------------------------------------------------------------------------
+    def step_ops(self, latents, n_lat):
+        """The launches of one forward on the current stream, reading the timestep from self.t_dev[0] (device) and the
+        noisy embeddings from `latents` (device fp32 [n_lat][E], sample b uses row b % n_lat): time embedding ->
+        sequence assembly -> proj_in into its row -> the transformer body.  No host-side value is baked in, so the
+        list can be captured in a hipGraph and replayed."""
+        B, L, C, E = self.B, self.L, self.C, self.E
+        return [
+            lambda: hip.timestep_embed(self.t_dev.data_ptr(), 1, C, self.temb0.data_ptr()),
+            lambda: hip.small_linear(self.temb0.data_ptr(), 1, C, self.w_t1.data_ptr(), self.b_t1.data_ptr(), C, 0, 1,
+                                     self.temb1.data_ptr()),
+            lambda: hip.small_linear(self.temb1.data_ptr(), 1, C, self.w_t2.data_ptr(), self.b_t2.data_ptr(), C, 0, 0,
+                                     self.temb2.data_ptr()),
+            lambda: hip.prior_assemble(self.base.data_ptr(), self.temb2.data_ptr(), latents.data_ptr(), n_lat, self.tok.ptr,
+                                       self.x16.ptr, B, L, C, E, L - 3),
+            lambda: hip.gemm(self._d_in, self.x16.ptr, self.w_in.data_ptr(), self.b_in.data_ptr(), 0, 0,
+                             self.tok.ptr + (L - 2) * C * 2, 0, 0),
+            self.plan.run,
+        ]
+
     @torch.no_grad()
     def forward(self, hidden_states, timestep):
+        """MyPriorTransformer.forward for one (hidden_states (B, E), scalar timestep) -> (B, clip_dim) fp32."""
         if self.ctx_key is None:
             raise hip.RcdmError("PriorProgram.forward before set_context")
-        B, L, C = self.B, self.L, self.C
-        dev = self.device
-        t = torch.as_tensor(timestep, dtype=torch.float32, device=dev).reshape(-1)
-        if t.numel() not in (1, B):
-            raise ValueError(f"timestep must be a scalar or have {B} entries")
-        tok3 = self.tok.buf.t[:B * L * C * 2].view(torch.float16).view(B, L, C)
-        tok3.copy_(self.base.view(B, L, C))
-        # time embedding: Timesteps(C) -> linear_1 -> SiLU -> linear_2 (+ positional embedding of its row); rows <= 8 per call
-        t = t.expand(B) if t.numel() == 1 else t
-        uniq = t[:1] if bool((t == t[0]).all()) else t
-        for r0 in range(0, uniq.numel(), 8):
-            r = min(8, uniq.numel() - r0)
-            self.t_dev[:r] = uniq[r0:r0 + r]
-            hip.timestep_embed(self.t_dev.data_ptr(), r, C, self.temb0.data_ptr())
-            hip.small_linear(self.temb0.data_ptr(), r, C, self.w_t1.data_ptr(), self.b_t1.data_ptr(), C, 0, 1,
-                             self.temb1.data_ptr())
-            hip.small_linear(self.temb1.data_ptr(), r, C, self.w_t2.data_ptr(), self.b_t2.data_ptr(), C, 0, 0,
-                             self.temb2.data_ptr())
-            if uniq.numel() == 1:
-                tok3[:, L - 3] = self.temb2[0].to(torch.float16)
-            else:
-                tok3[r0:r0 + r, L - 3] = self.temb2[:r].to(torch.float16)
-        # noisy embedding row: proj_in(hidden_states) + bias + positional embedding, written straight into its row
-        x32 = hidden_states.detach().to(dev, torch.float32).contiguous()
+        B = self.B
+        t = torch.as_tensor(timestep, dtype=torch.float32, device=self.device).reshape(-1)
+        if t.numel() != 1 and not bool((t == t[0]).all()):
+            raise NotImplementedError("per-sample timesteps: the reference pipeline passes one scalar per step "
+                                      "(prior_pipeline.py:317)")
+        self.t_dev[:1] = t[:1]
+        x32 = hidden_states.detach().to(self.device, torch.float32).contiguous()
         if tuple(x32.shape) != (B, self.E):
             raise hip.RcdmError(f"hidden_states shape {tuple(x32.shape)} != {(B, self.E)}")
-        hip.pack_f16(x32.data_ptr(), self.x16.ptr, x32.numel())
-        d = hip.GemmDesc(B, C, self.E, self.E, L * C, 0, hip.EPI_BIAS, 1, 0, 1.0, 1)
-        hip.gemm(d, self.x16.ptr, self.w_in.data_ptr(), self.b_in.data_ptr(), 0, 0, self.tok.ptr + (L - 2) * C * 2, 0, 0)
-        self.plan.run()
-        out = self.out16.buf.t[:B * self.clip_dim * 2].view(torch.float16).view(B, self.clip_dim)
-        return out.float()
+        for op in self.step_ops(x32, B):
+            op()
+        torch.cuda.current_stream(self.device).synchronize()   # x32 must outlive the launches
+        return self.out_rows().float()
+
+    def out_rows(self):
+        """(B, clip_dim) f16 view of the predicted embeddings."""
+        return self.out16.buf.t[:self.B * self.clip_dim * 2].view(torch.float16).view(self.B, self.clip_dim)

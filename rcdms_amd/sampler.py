@@ -103,3 +103,90 @@ class DenoiseLoop:
                     callback(i, int(self.timesteps[i]), self.lat)
         cur.wait_stream(p.stream)
         return self.lat
+
+
+class PriorLoop:
+    """The stage-1 sampling loop (reference: `for i, t in enumerate(timesteps)` of Seq_Inpaint_Prior_Pipeline.__call__,
+    src/pipelines/prior_pipeline.py:311-344) as T replays of one captured hipGraph: [load t | time embedding | sequence
+    assembly | ~600 transformer launches | CFG combine + UnCLIP step | step++].  The scheduler's noise for all T steps is
+    drawn up front (from the caller's generator, or supplied), so the captured step is a pure function of device state."""
+
+    def __init__(self, prior, frames, num_text_tokens, guidance_scale, scheduler, num_steps):
+        self.prior = prior
+        self.gs = float(guidance_scale)
+        self.reps = 2 if guidance_scale > 1.0 else 1   # do_classifier_free_guidance, prior_pipeline.py:236-238
+        self.n = int(frames)
+        self.T = int(num_steps)
+        dev = prior.device
+        self.device = dev
+        if not hasattr(scheduler, "coefficients") or not hasattr(scheduler, "alphas_cumprod"):
+            raise NotImplementedError(f"{type(scheduler).__name__}: only rcdms_amd.scheduler.UnCLIPScheduler has a fused step")
+        if scheduler.config.prediction_type != "sample":
+            raise NotImplementedError("the prior predicts the sample (Kandinsky-2.2 prior scheduler config)")
+        scheduler.set_timesteps(self.T, device=None)
+        self.timesteps = torch.as_tensor(scheduler.timesteps).to("cpu", torch.int64)
+        self.coef = scheduler.coefficients().to(dev)
+        self.clip = float(scheduler.config.clip_sample_range) if scheduler.config.clip_sample else 0.0
+        self.ts_dev = self.timesteps.to(torch.float32).to(dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.init_noise_sigma = float(getattr(scheduler, "init_noise_sigma", 1.0))
+        B = self.reps * self.n
+        self.prog = prior._program(B, num_text_tokens)
+        E = self.prog.E
+        self.lat = torch.zeros(self.n, E, dtype=torch.float32, device=dev)
+        self.noise = torch.zeros(self.T, self.n, E, dtype=torch.float32, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        p = self.prog
+        self._ops = ([lambda: hip.load_timestep(self.ts_dev.data_ptr(), self.step_dev.data_ptr(), p.t_dev.data_ptr(), 1)]
+                     + p.step_ops(self.lat, self.n)
+                     + [lambda: hip.cfg_unclip_step(p.out16.ptr, p.out16.ld, self.lat.data_ptr(), self.n, self.reps, E,
+                                                    self.gs, self.clip, self.coef.data_ptr(), self.noise.data_ptr(),
+                                                    self.step_dev.data_ptr()),
+                        lambda: hip.advance_step(self.step_dev.data_ptr())])
+        self.graph = None
+
+    def load(self, latents, proj_embedding, encoder_hidden_states, proj_embedding1, mask_label, attention_mask,
+             noise=None, generator=None):
+        """Stage the inputs in HBM.  latents (n, E) initial noise; the conditioning tensors already hold the CFG batch
+        (B = reps * n rows, unconditional half first, as the reference's _encode_prompt / torch.cat([x] * 2) produce)."""
+        assert tuple(latents.shape) == tuple(self.lat.shape), (latents.shape, self.lat.shape)
+        self.lat.copy_(latents.to(self.device, torch.float32) * self.init_noise_sigma)
+        if noise is None:
+            noise = torch.randn(self.noise.shape, dtype=torch.float32, device=self.device, generator=generator)
+        self.noise.copy_(noise.to(self.device, torch.float32))
+        self.prog.set_context(proj_embedding, encoder_hidden_states, proj_embedding1, mask_label, attention_mask)
+        self.step_dev.zero_()
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def _one_step_eager(self):
+        for op in self._ops:
+            op()
+
+    def run(self, use_graph=True):
+        """All T steps; returns the final latents (n, E) fp32 on the device (before post_process_latents)."""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            if use_graph and self.graph is None:
+                lat0 = self.lat.clone()
+                self._one_step_eager()        # load every kernel once outside capture, then restore the state
+                self.lat.copy_(lat0)
+                self.step_dev.zero_()
+                self.stream.synchronize()
+                g = hip.Graph()
+                g.begin()
+                try:
+                    self._one_step_eager()
+                finally:
+                    g.end()
+                self.stream.synchronize()
+                self.step_dev.zero_()
+                self.lat.copy_(lat0)
+                self.graph = g
+            for _ in range(self.T):
+                if use_graph:
+                    self.graph.launch()
+                else:
+                    self._one_step_eager()
+        cur.wait_stream(self.stream)
+        return self.lat

@@ -104,3 +104,103 @@ class DDIMScheduler:
         if not return_dict:
             return (prev_sample,)
         return DDIMSchedulerOutput(prev_sample=prev_sample, pred_original_sample=x0)
+
+
+@dataclass
+class UnCLIPSchedulerOutput:
+    prev_sample: torch.Tensor
+    pred_original_sample: torch.Tensor = None
+
+
+class UnCLIPScheduler:
+    """The stage-1 prior's scheduler (reference: `UnCLIPScheduler.from_pretrained(..., subfolder="scheduler")`,
+    stage1_batchtest_rcdms_model.py:101; used at src/pipelines/prior_pipeline.py:293-294,338-344).
+
+    Arithmetic of diffusers==0.24.0 `UnCLIPScheduler` (not vendored, not installed: restated, "parity unpinned"):
+    squaredcos_cap_v2 betas, timesteps = round(arange(n) * (N-1)/(n-1))[::-1], and `step` for prediction_type "sample" |
+    "epsilon" with variance_type "fixed_small_log".  Defaults are the published Kandinsky-2.2 prior scheduler config
+    (clip_sample True, clip_sample_range 10, prediction_type "sample").  `coefficients()` gives the per-step
+    (k0, k1, k2) of  prev = k0 x0 + k1 x_t + k2 noise  that the fused rcdm_cfg_unclip_step kernel consumes."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, variance_type="fixed_small_log", clip_sample=True, clip_sample_range=10.0,
+                 prediction_type="sample", beta_schedule="squaredcos_cap_v2"):
+        if variance_type != "fixed_small_log" or beta_schedule != "squaredcos_cap_v2":
+            raise NotImplementedError("UnCLIPScheduler: fixed_small_log / squaredcos_cap_v2 only (the prior's config)")
+        if prediction_type not in ("sample", "epsilon"):
+            raise NotImplementedError(f"prediction_type {prediction_type}")
+        self._internal_dict = _FrozenDict(num_train_timesteps=num_train_timesteps, variance_type=variance_type,
+                                          clip_sample=clip_sample, clip_sample_range=clip_sample_range,
+                                          prediction_type=prediction_type, beta_schedule=beta_schedule)
+        import math
+        ab = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+        n = num_train_timesteps
+        betas = [min(1 - ab((i + 1) / n) / ab(i / n), 0.999) for i in range(n)]
+        self.betas = torch.tensor(betas, dtype=torch.float64)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.timesteps = torch.arange(n - 1, -1, -1, dtype=torch.int64)
+        self.num_inference_steps = None
+
+    @property
+    def config(self):
+        return self._internal_dict
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        n = self.config.num_train_timesteps
+        ratio = (n - 1) / (num_inference_steps - 1)
+        import numpy as np
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts).to(device) if device is not None else torch.from_numpy(ts)
+
+    def _coef(self, t, prev_t):
+        ac = self.alphas_cumprod
+        a_t = ac[t]
+        a_prev = ac[prev_t] if prev_t >= 0 else torch.tensor(1.0, dtype=torch.float64)
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        if prev_t == t - 1:
+            beta, alpha = self.betas[t], self.alphas[t]
+        else:
+            beta = 1 - a_t / a_prev
+            alpha = 1 - beta
+        k0 = a_prev.sqrt() * beta / b_t
+        k1 = alpha.sqrt() * b_prev / b_t
+        std = torch.tensor(0.0, dtype=torch.float64)
+        if t > 0:
+            var = torch.clamp(b_prev / b_t * beta, min=1e-20)
+            std = torch.exp(0.5 * torch.log(var))
+        return k0, k1, std, a_t, b_t
+
+    def coefficients(self):
+        """fp32 [n_steps][3] = (k0, k1, std) for the current timesteps (prev_timestep = the next entry, None at the end:
+        prior_pipeline.py:335-338)."""
+        ts = self.timesteps.tolist()
+        rows = []
+        for i, t in enumerate(ts):
+            prev = ts[i + 1] if i + 1 < len(ts) else t - 1
+            k0, k1, std, _, _ = self._coef(t, prev)
+            rows.append([float(k0), float(k1), float(std)])
+        return torch.tensor(rows, dtype=torch.float32)
+
+    def step(self, model_output, timestep, sample, prev_timestep=None, generator=None, return_dict=True, noise=None):
+        t = int(timestep)
+        prev_t = t - 1 if prev_timestep is None else int(prev_timestep)
+        k0, k1, std, a_t, b_t = self._coef(t, prev_t)
+        if self.config.prediction_type == "epsilon":
+            x0 = (sample - b_t.sqrt().to(sample.dtype) * model_output) / a_t.sqrt().to(sample.dtype)
+        else:
+            x0 = model_output
+        if self.config.clip_sample:
+            x0 = torch.clamp(x0, -self.config.clip_sample_range, self.config.clip_sample_range)
+        prev = k0.to(sample.dtype) * x0 + k1.to(sample.dtype) * sample
+        if t > 0:
+            if noise is None:
+                noise = torch.randn(model_output.shape, dtype=model_output.dtype, device=model_output.device,
+                                    generator=generator)
+            prev = prev + std.to(sample.dtype) * noise
+        return UnCLIPSchedulerOutput(prev_sample=prev, pred_original_sample=x0) if return_dict else (prev,)

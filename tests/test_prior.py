@@ -95,3 +95,58 @@ def test_hip_prior_vs_reference(name):
                                 *(inputs(name, E, seed)[k] for k in ("proj_embedding", "encoder_hidden_states",
                                                                      "proj_embedding1", "mask_label", "attention_mask")))
         assert float(((out2 - ref2) ** 2).mean().sqrt() / (ref2 ** 2).mean().sqrt()) <= 1e-2
+
+
+def test_unclip_scheduler_known_answers():
+    """diffusers UnCLIPScheduler arithmetic restated (parity unpinned): closed-form checks."""
+    from rcdms_amd.scheduler import UnCLIPScheduler
+    s = UnCLIPScheduler()
+    s.set_timesteps(25)
+    ts = s.timesteps.tolist()
+    assert ts[0] == 999 and ts[-1] == 0 and len(ts) == 25 and ts == sorted(ts, reverse=True)
+    assert ts[1] == round(23 * 999 / 24)
+    k = s.coefficients()
+    assert k.shape == (25, 3)
+    assert float(k[-1, 2]) == 0.0 and abs(float(k[-1, 0]) - 1.0) < 1e-6 and abs(float(k[-1, 1])) < 1e-6  # t = 0: x0
+    # one step equals the posterior mean formula of DDPM with the "sample" parameterisation
+    x0, xt = torch.full((2, 3), 0.5), torch.full((2, 3), -1.0)
+    out = s.step(x0, ts[3], xt, prev_timestep=ts[4], noise=torch.zeros(2, 3)).prev_sample
+    ac = s.alphas_cumprod
+    a_t, a_p = ac[ts[3]], ac[ts[4]]
+    beta = 1 - a_t / a_p
+    want = (a_p.sqrt() * beta / (1 - a_t)) * 0.5 + ((1 - beta).sqrt() * (1 - a_p) / (1 - a_t)) * -1.0
+    assert torch.allclose(out, torch.full((2, 3), float(want)), atol=1e-6)
+    big = s.step(torch.full((1, 2), 50.0), ts[3], torch.zeros(1, 2), prev_timestep=ts[4], noise=torch.zeros(1, 2))
+    assert float(big.pred_original_sample.max()) == 10.0          # clip_sample_range
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("guidance", [4.0, 1.0])
+def test_hip_prior_loop_vs_oracle(guidance):
+    """5 replays of the captured step graph (time embedding -> assembly -> transformer -> CFG + UnCLIP step) vs the
+    oracle's restatement of prior_pipeline.py:293-344 with the same injected scheduler noise; eager == graph."""
+    from rcdms_amd.sampler import PriorLoop
+    from rcdms_amd.scheduler import UnCLIPScheduler
+    m, g, cfg, E = build("prior_tiny")
+    seed = int(g["seed"])
+    sd = synth.procedural_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed)
+    m.load_state_dict(sd)
+    m = m.to("cuda")
+    reps = 2 if guidance > 1 else 1
+    x = inputs("prior_tiny", E, seed, B=5 * reps)
+    T = 5
+    lat0 = synth.normal_tensor("prior_loop.lat", (5, E), seed)
+    noise = synth.normal_tensor("prior_loop.noise", (T, 5, E), seed)
+    loop = PriorLoop(m, 5, 91, guidance, UnCLIPScheduler(), T)
+    args = [x[k] for k in ("proj_embedding", "encoder_hidden_states", "proj_embedding1", "mask_label", "attention_mask")]
+    loop.load(lat0, *args, noise=noise)
+    out = loop.run().clone().float().cpu()
+    ref = PO.prior_denoise_loop(sd, cfg, UnCLIPScheduler(), lat0, *args, T, guidance, noise)
+    rel = float(((out - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+    print(f"prior loop gs={guidance}: rel-RMS {rel:.3e}")
+    assert torch.isfinite(out).all() and rel <= 1e-2, rel
+    loop.load(lat0, *args, noise=noise)
+    out2 = loop.run().clone().float().cpu()
+    loop.load(lat0, *args, noise=noise)
+    out3 = loop.run(use_graph=False).clone().float().cpu()
+    assert torch.equal(out, out2) and torch.equal(out, out3)
