@@ -45,8 +45,10 @@ def inputs(name, E, seed, B=10, T=91):
                 mask_label=t("mask_label", (B, E)), attention_mask=am)
 
 
-def test_state_dict_layout_is_the_reference_layout():
-    m, g, _, _ = build("prior_tiny")
+@pytest.mark.parametrize("name", CASES)
+def test_state_dict_layout_is_the_reference_layout(name):
+    with torch.device("meta"):
+        m, g, _, _ = build(name)
     assert key_digest(m.state_dict()) == str(g["key_digest"]), "mirrored MyPriorTransformer keys/shapes differ"
 
 
