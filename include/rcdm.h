@@ -67,8 +67,9 @@ typedef struct {
 } rcdm_gemm_desc;
 
 size_t rcdm_gemm_workspace_bytes(const rcdm_gemm_desc* d);
-/* tuning/test knob for rcdm_gemm and rcdm_conv3x3: -1 = automatic (default; env RCDM_IGEMM=dma128|dma256
- * overrides), 1 = 128x128, 2 = 256x256 (pixels x channels) tiles.
+/* tuning/test knob for rcdm_gemm and rcdm_conv3x3: -1 = automatic (default: chosen per shape; env
+ * RCDM_IGEMM=dma128|dma256|dma64 overrides), tile (pixels x channels): 1 = 128x128, 2 = 256x256, 3 = 64x64,
+ * 4 = 64x64 with a four-slot LDS ring, 5 = 128x64.
  * Changes the workspace size a shape needs: query rcdm_*_workspace_bytes after setting it. */
 int rcdm_set_igemm_variant(int32_t variant);
 /* debug: when non-NULL, every igemm block writes 4 int64 {start, end (s_memtime ticks), ticks spent in epilogues,
