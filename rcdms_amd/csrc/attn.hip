@@ -352,6 +352,7 @@ struct TAttnArgs {
   const f16* qkv;
   f16* out;
   int samples, pixels, heads, d, ldqkv, ldo, tpb;
+  int g;  // lanes per (pixel, head, query frame) item: 1, 2, 4 or 8 adjacent lanes split the head dim
   float scale;
 };
 
@@ -384,17 +385,19 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs p) {
   }
   __syncthreads();
 
-  // ---- compute: lane = (pl, head, i) ----------------------------------------------------------------------
+  // ---- compute: item = (pl, head, i); its p.g adjacent lanes take every p.g-th 16-B chunk of the head dim (wide heads
+  // with one pixel per block would otherwise leave most of the block idle), partial scores meet in a xor-butterfly
   const int items = p.tpb * p.heads * F;
-  if (t < items) {
-    const int i = t % F, ph = t / F;
+  const int sub = t % p.g, item = t / p.g;
+  if (item < items) {
+    const int i = item % F, ph = item / F;
     const int head = ph % p.heads, pl = ph / p.heads;
     f16* base = tile + (size_t)pl * F * C3 + head * p.d;
     f16* qrow = base + (size_t)i * C3;
     float s[F];
 #pragma unroll
     for (int j = 0; j < F; ++j) s[j] = 0.f;
-    for (int c = 0; c < p.d; c += 8) {
+    for (int c = sub * 8; c < p.d; c += 8 * p.g) {
       Pack16 qv;
       qv.u = *(const uint4*)(qrow + c);
 #pragma unroll
@@ -406,6 +409,10 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs p) {
         for (int e = 0; e < 8; ++e) acc = fmaf((float)qv.e[e], (float)kv.e[e], acc);
         s[j] = acc;
       }
+    }
+    for (int off = 1; off < p.g; off <<= 1) {
+#pragma unroll
+      for (int j = 0; j < F; ++j) s[j] += __shfl_xor(s[j], off, 64);
     }
     float mx = s[0] * p.scale;
 #pragma unroll
@@ -420,7 +427,9 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs p) {
       sum += s[j];
     }
     const float inv = __builtin_amdgcn_rcpf(sum);
-    for (int c = 0; c < p.d; c += 8) {
+    // every lane of the item has finished reading q (the butterfly above is a wave-level rendezvous), so the item's
+    // q segment can take the output
+    for (int c = sub * 8; c < p.d; c += 8 * p.g) {
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = 0.f;
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs p) {
       Pack16 ov;
 #pragma unroll
       for (int e = 0; e < 8; ++e) ov.e[e] = (f16)o[e];
-      *(uint4*)(qrow + c) = ov.u;  // this lane's own q segment: nobody else reads it
+      *(uint4*)(qrow + c) = ov.u;  // this item's own q segment: no other item reads it
     }
   }
   __syncthreads();
@@ -501,6 +510,9 @@ int rcdm_temporal_attn(const rcdm_temporal_attn_desc* d, const void* qkv, void* 
   if (tpb < 1) tpb = 1;
   if ((size_t)tpb * px_bytes > 160 * 1024 || d->heads * d->frames > 256) return RCDM_ESHAPE;
   a.tpb = tpb;
+  int g = 8;  // as many lanes per item as the block and the head dim allow
+  while (g > 1 && (tpb * d->heads * d->frames * g > 256 || d->d / 8 < g)) g >>= 1;
+  a.g = g;
   const size_t lds = (size_t)tpb * px_bytes;
   hipStream_t stream = (hipStream_t)stream_;
   const long total_px = (long)d->samples * d->pixels;

@@ -48,6 +48,11 @@ GEMMS = [  # (name, M, N, K, epi)
     ("L1 ctx kv N=1280 K=768", 850, 1280, 768, 0),
     ("L2 ctx kv N=2560 K=768", 850, 2560, 768, 0),
     ("L1 qkv N=1920", 10240, 1920, 640, 0),
+    ("prior CxC 2048", 970, 2048, 2048, 5),
+    ("prior qkv N=6144", 970, 6144, 2048, 1),
+    ("prior ff1 gelu N=8192", 970, 8192, 2048, 17),
+    ("prior ff2 K=8192", 970, 2048, 8192, 5),
+    ("prior geglu N=16384", 970, 16384, 2048, 9),
 ]
 CONVS = [  # (name, n_img, H, W, cin, cout)
     ("L0 320->320 @64", 10, 64, 64, 320, 320),
