@@ -152,3 +152,82 @@ def test_hip_prior_loop_vs_oracle(guidance):
     loop.load(lat0, *args, noise=noise)
     out3 = loop.run(use_graph=False).clone().float().cpu()
     assert torch.equal(out, out2) and torch.equal(out, out3)
+
+
+@pytest.mark.gpu
+def test_prior_pipeline_call_matches_oracle_flow():
+    """Seq_Inpaint_Prior_Pipeline.__call__ end to end (prior_pipeline.py:245-374) with stand-in CLIP modules: prompt
+    encoding with the unconditional half first, CFG duplication of the image conditioning, the captured sampling loop,
+    post_process_latents — against the oracle loop fed the noise the pipeline's generator draws."""
+    import types
+    from torch import nn
+    from rcdms_amd.scheduler import UnCLIPScheduler
+    from src.pipelines.prior_pipeline import Seq_Inpaint_Prior_Pipeline
+    m, g, cfg, E = build("prior_tiny")
+    seed = int(g["seed"])
+    sd = synth.procedural_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed)
+    m.load_state_dict(sd)
+    T = 91
+
+    class Tok:
+        def __call__(self, texts, padding=None, max_length=T, truncation=True, return_tensors="pt"):
+            ids = torch.zeros(len(texts), max_length, dtype=torch.long)
+            am = torch.zeros(len(texts), max_length, dtype=torch.long)
+            for i, s in enumerate(texts):
+                n = min(len(s), max_length - 2)
+                ids[i, 0], am[i, 0] = 98, 1
+                for j in range(n):
+                    ids[i, 1 + j], am[i, 1 + j] = 1 + ord(s[j]) % 90, 1
+                ids[i, 1 + n], am[i, 1 + n] = 99, 1
+            return types.SimpleNamespace(input_ids=ids, attention_mask=am)
+
+    class Text(nn.Module):
+        max_position_embeddings = T
+
+        def __init__(self):
+            super().__init__()
+            self.emb = nn.Embedding(100, E)
+            with torch.no_grad():
+                self.emb.weight.copy_(synth.normal_tensor("prior_e2e.emb", (100, E), 3))
+
+        def forward(self, ids):
+            h = self.emb(ids)
+            return types.SimpleNamespace(text_embeds=h.mean(1), last_hidden_state=h)
+
+    class Img(nn.Module):
+        config = types.SimpleNamespace(image_size=8)
+        dtype = torch.float32
+
+        def forward(self, x):
+            return {"image_embeds": torch.zeros(x.shape[0], E, device=x.device)}
+
+    tok, text = Tok(), Text()
+    pipe = Seq_Inpaint_Prior_Pipeline(prior=m, image_encoder=Img(), text_encoder=text, tokenizer=tok,
+                                      scheduler=UnCLIPScheduler()).to("cuda")
+    caps = ["pororo waves", "loopy sings a song", "eddy builds", "crong", "poby fishes today"]
+    img_proj = synth.normal_tensor("prior_e2e.img", (5, E), 4)
+    mlabel = synth.normal_tensor("prior_e2e.ml", (5, E), 5)
+    lat0 = synth.normal_tensor("prior_e2e.lat", (5, E), 6)
+    steps, gs = 4, 4.0
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    out = pipe(caps, img_proj.cuda(), mlabel.cuda(), video_length=5, num_inference_steps=steps, guidance_scale=gs,
+               latents=lat0.cuda(), generator=gen)
+    got = out.image_embeds.float().cpu()
+    assert tuple(got.shape) == (5, E) and tuple(out.negative_image_embeds.shape) == (5, E)
+    noise = torch.randn((steps, 5, E), dtype=torch.float32, device="cuda",
+                        generator=torch.Generator(device="cuda").manual_seed(7)).cpu()
+    emb = text.emb.weight.detach().cpu()
+
+    def enc(texts):
+        t = tok(texts)
+        h = emb[t.input_ids]
+        return h.mean(1), h, t.attention_mask.float()
+
+    ue, uh, um = enc([""] * 5)
+    ce, ch, cm = enc(caps)
+    ref = PO.prior_denoise_loop(sd, cfg, UnCLIPScheduler(), lat0, torch.cat([ue, ce]), torch.cat([uh, ch]),
+                                torch.cat([img_proj] * 2), torch.cat([mlabel] * 2), torch.cat([um, cm]), steps, gs, noise)
+    ref = ref * 0.415 + -0.016                                      # post_process_latents (:413-415)
+    rel = float(((got - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+    print(f"prior pipeline e2e: rel-RMS {rel:.3e}")
+    assert rel <= 1e-2, rel
