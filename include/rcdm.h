@@ -177,6 +177,14 @@ typedef struct {
 int rcdm_temporal_attn(const rcdm_temporal_attn_desc* d, const void* qkv, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Row softmax: y[m][n] = softmax over n of (scale * x[m][n]); f16 rows, fp32 math, N % 8 == 0, N <= 4096, scale > 0.
+ *   With two rcdm_gemm calls (scores = Q K^T, out = P V^T^T) it is the attention of heads too wide for
+ *   rcdm_flash_attn: the single 512-channel head of the SD-1.5 VAE mid block (diffusers 0.24.0 AutoencoderKL,
+ *   called at RCDMs_pipeline.py:281,429 — SURVEY §8f N3).
+ * ---------------------------------------------------------------------------------------------- */
+int rcdm_softmax_rows(int32_t M, int32_t N, int32_t ldx, int32_t ldy, float scale, const void* x, void* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Timestep embedding: diffusers 0.24.0 Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) as used
  *   at unet.py:100,383: out[r][0:half] = cos(t_r*w_i), out[r][half:] = sin(t_r*w_i),
  *   w_i = exp(-ln(10000)*i/half).  t fp32 device array [rows]; out fp32 [rows][dim].

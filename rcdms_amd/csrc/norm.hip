@@ -270,6 +270,54 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
   }
 }
 
+// Row softmax over f16 rows (fp32 math): y[m][n] = softmax_n(scale * x[m][n]).  One wave per row, the row held in
+// registers across the max / sum passes.  Used where a head dim is too wide for the flash kernel (the VAE mid-block
+// attention: one head of 512 channels over 64 x 64 tokens), where scores are materialised by two GEMMs instead.
+template <int NCH>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict__ x, f16* __restrict__ y, int M, int N,
+                                                           int ldx, int ldy, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunks = N >> 3;
+  const float c = scale * 1.4426950408889634f;
+  Pack16 raw[NCH];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunks) {
+      raw[i].u = *(const uint4*)(x + (size_t)row * ldx + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)raw[i].e[e]);
+    }
+  }
+  mx = wave_max(mx) * c;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    if (lane + 64 * i < nchunks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = __builtin_amdgcn_exp2f(fmaf((float)raw[i].e[e], c, -mx));
+        sum += v[i][e];
+      }
+    }
+  }
+  const float inv = __builtin_amdgcn_rcpf(wave_sum(sum));
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunks) {
+      Pack16 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.e[e] = (f16)(v[i][e] * inv);
+      *(uint4*)(y + (size_t)row * ldy + ch * 8) = o.u;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -329,6 +377,24 @@ int rcdm_layernorm(const rcdm_layernorm_desc* d, const void* x, const float* gam
     default: LN_LAUNCH(4, 1); break;
   }
 #undef LN_LAUNCH
+  return rcdm_check_launch();
+}
+
+int rcdm_softmax_rows(int32_t M, int32_t N, int32_t ldx, int32_t ldy, float scale, const void* x, void* y, void* stream_) {
+  if (!x || !y || M <= 0 || N <= 0) return RCDM_EINVAL;
+  if ((N & 7) || N > 4096 || (ldx & 7) || (ldy & 7) || scale <= 0.f) return RCDM_ESHAPE;  // scale > 0: max first
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nch = ((N >> 3) + 63) / 64;
+#define SM_LAUNCH(NCH_)                                                                                  \
+  hipLaunchKernelGGL((softmax_rows_kernel<NCH_>), dim3((M + 3) / 4), dim3(256), 0, stream, (const f16*)x, \
+                     (f16*)y, M, N, ldx, ldy, scale)
+  switch (nch) {
+    case 1: SM_LAUNCH(1); break;
+    case 2: SM_LAUNCH(2); break;
+    case 3: case 4: SM_LAUNCH(4); break;
+    default: SM_LAUNCH(8); break;
+  }
+#undef SM_LAUNCH
   return rcdm_check_launch();
 }
 

@@ -70,6 +70,7 @@ SYMBOLS = {
     "rcdm_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_groupnorm_workspace_bytes": (_SZ, [C.POINTER(GroupNormDesc)]),
     "rcdm_groupnorm_silu": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _SZ, _P]),
+    "rcdm_softmax_rows": (C.c_int, [_I, _I, _I, _I, C.c_float, _P, _P, _P]),
     "rcdm_layernorm": (C.c_int, [C.POINTER(LayerNormDesc), _P, _P, _P, _P, _P, _P]),
     "rcdm_flash_attn": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
     "rcdm_flash_attn_masked": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _I, _P, _P]),
@@ -173,6 +174,11 @@ def groupnorm_silu(desc, x, gamma, beta, y, ws_ptr, ws_bytes, stream=None):
 def layernorm(desc, x, gamma, beta, pe, y, stream=None):
     _check(load().rcdm_layernorm(C.byref(desc), x, gamma, beta, pe, y,
                                  stream_ptr() if stream is None else stream), "rcdm_layernorm")
+
+
+def softmax_rows(M, N, ldx, ldy, scale, x, y, stream=None):
+    _check(load().rcdm_softmax_rows(M, N, ldx, ldy, scale, x, y, stream_ptr() if stream is None else stream),
+           "rcdm_softmax_rows")
 
 
 def flash_attn(desc, q, k, v, out, stream=None):

@@ -53,7 +53,8 @@ class RCDMsPipeline:
     _optional_components = []
     FRAMES = 5  # hard-coded in the reference (:261,:430,:476); the PE table of the motion modules has 5 rows
 
-    def __init__(self, vae, text_encoder, tokenizer, unet: UNet3DConditionModel, local_module, global_module, scheduler):
+    def __init__(self, vae, text_encoder, tokenizer, unet: UNet3DConditionModel, local_module, global_module, scheduler,
+                 vae_decoder=None):
         # the two scheduler-config mutations of the reference ctor (:84-109)
         if hasattr(scheduler, "config"):
             if hasattr(scheduler.config, "steps_offset") and scheduler.config.steps_offset != 1:
@@ -64,6 +65,9 @@ class RCDMsPipeline:
                 and unet.config.sample_size < 64 and hasattr(unet.config, "_diffusers_version"):
             _force_config(unet, "sample_size", 64)
         self.vae, self.text_encoder, self.tokenizer, self.unet = vae, text_encoder, tokenizer, unet
+        # optional rcdms_amd.vae.AutoencoderKLDecoder: decodes the 5 frames in one HIP launch plan instead of five
+        # `self.vae.decode` calls (:281); `vae` is still used for `encode`
+        self.vae_decoder = vae_decoder
         self.local_module, self.global_module, self.scheduler = local_module, global_module, scheduler
         boc = getattr(getattr(vae, "config", None), "block_out_channels", None)
         self.vae_scale_factor = 2 ** (len(boc) - 1) if boc is not None else 8
@@ -178,8 +182,11 @@ class RCDMsPipeline:
         """(:274-287) one frame at a time through the user's VAE."""
         f = latents.shape[2]
         latents = (1 / 0.18215 * latents).permute(0, 2, 1, 3, 4).reshape(-1, latents.shape[1], *latents.shape[3:])
-        frames = [self.vae.decode(latents[i:i + 1]).sample for i in range(latents.shape[0])]
-        video = torch.cat(frames)
+        if self.vae_decoder is not None:
+            video = self.vae_decoder.decode(latents).sample
+        else:
+            frames = [self.vae.decode(latents[i:i + 1]).sample for i in range(latents.shape[0])]
+            video = torch.cat(frames)
         video = video.reshape(-1, f, *video.shape[1:]).permute(0, 2, 1, 3, 4)
         return (video / 2 + 0.5).clamp(0, 1).cpu().float().numpy()
 
