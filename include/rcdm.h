@@ -97,6 +97,8 @@ typedef struct {
   int32_t rows_per_sample, ldt;
   float out_scale;
   int32_t split_k;
+  int32_t pad_after_only; /* 0: padding 1 on every side (default).  1: zero rows/columns only AFTER the image —
+                           * diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) then a stride-2 conv (VAE encoder) */
 } rcdm_conv3x3_desc;
 
 size_t rcdm_conv3x3_workspace_bytes(const rcdm_conv3x3_desc* d);

@@ -41,6 +41,7 @@ struct IgemmArgs {
   float* partial;
   int M, N, Cin, Ktot;
   int Hi, Wi, Ho, Wo, stride, up;
+  int pad;  // rows / columns of zero padding before the image: 1, or 0 for the pad-after-only form
   int lda, ldc, ldr, ldt, rows_per_sample;
   int epi;
   float out_scale;
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
         const int img = m / hw, rem = m - img * hw;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         a_img[i] = img;
-        a_iy[i] = m < p.M ? oy * p.stride - 1 : -(1 << 20);
-        a_ix[i] = ox * p.stride - 1;
+        a_iy[i] = m < p.M ? oy * p.stride - p.pad : -(1 << 20);
+        a_ix[i] = ox * p.stride - p.pad;
       }
     }
 #pragma unroll
@@ -668,7 +669,7 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
 
 void from_gemm(const rcdm_gemm_desc* d, IgemmArgs& a) {
   a.M = d->M; a.N = d->N; a.Cin = d->K; a.Ktot = d->K;
-  a.Hi = a.Wi = a.Ho = a.Wo = 1; a.stride = 1; a.up = 0;
+  a.Hi = a.Wi = a.Ho = a.Wo = 1; a.stride = 1; a.up = 0; a.pad = 1;
   a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.ldt = d->ldt;
   a.rows_per_sample = d->rows_per_sample; a.epi = d->epilogue; a.out_scale = d->out_scale;
 }
@@ -681,6 +682,11 @@ int from_conv(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
   a.Ho = (hv - 1) / d->stride + 1;
   a.Wo = (wv - 1) / d->stride + 1;
   a.Hi = d->h_in; a.Wi = d->w_in; a.stride = d->stride; a.up = d->upsample;
+  if (d->pad_after_only != 0 && d->pad_after_only != 1) return RCDM_ESHAPE;
+  // F.pad(x, (0,1,0,1)) + a stride-2 conv without padding: (h + 1 - 3) / 2 + 1 = h / 2 rows for even h — the same
+  // count as the symmetric form; odd sizes would differ, and the form only exists for stride 2
+  if (d->pad_after_only && (d->stride != 2 || d->upsample || (d->h_in & 1) || (d->w_in & 1))) return RCDM_ESHAPE;
+  a.pad = d->pad_after_only ? 0 : 1;
   a.M = d->n_img * a.Ho * a.Wo; a.N = d->c_out; a.Cin = d->c_in; a.Ktot = 9 * d->c_in;
   a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.ldt = d->ldt;
   a.rows_per_sample = d->rows_per_sample; a.epi = d->epilogue; a.out_scale = d->out_scale;

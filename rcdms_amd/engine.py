@@ -129,7 +129,7 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
 
 
 def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=None, rowvec=None, residual=None,
-                 scale=1.0, split_k=0):
+                 scale=1.0, split_k=0, pad_after_only=0):
     epi = 0
     if bias is not None:
         epi |= hip.EPI_BIAS
@@ -138,7 +138,7 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
     if residual is not None:
         epi |= hip.EPI_RESIDUAL
     d = hip.ConvDesc(n_img, H, W, cin, cout, stride, up, x.ld, out.ld, residual.ld if residual is not None else 0,
-                     epi, rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k)
+                     epi, rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k, pad_after_only)
     wsb = hip.conv3x3_workspace_bytes(d)
     ws = plan.scratch("splitk_ws", max(wsb, 256))
     bptr = bias.data_ptr() if bias is not None else 0

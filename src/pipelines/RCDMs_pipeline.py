@@ -66,7 +66,11 @@ class RCDMsPipeline:
             _force_config(unet, "sample_size", 64)
         self.vae, self.text_encoder, self.tokenizer, self.unet = vae, text_encoder, tokenizer, unet
         # optional rcdms_amd.vae.AutoencoderKLDecoder: decodes the 5 frames in one HIP launch plan instead of five
-        # `self.vae.decode` calls (:281); `vae` is still used for `encode`
+        # `self.vae.decode` calls (:281); `vae` is still used for `encode`.  Passing rcdms_amd.vae.AutoencoderKL as
+        # `vae` itself puts both halves on the HIP path.
+        from rcdms_amd.vae import AutoencoderKLDecoder
+        if vae_decoder is None and isinstance(vae, AutoencoderKLDecoder):
+            vae_decoder = vae
         self.vae_decoder = vae_decoder
         self.local_module, self.global_module, self.scheduler = local_module, global_module, scheduler
         boc = getattr(getattr(vae, "config", None), "block_out_channels", None)

@@ -56,8 +56,12 @@ class _Vae(nn.Module):
         return types.SimpleNamespace(sample=nn.functional.interpolate(z[:, :3], scale_factor=8, mode="nearest"))
 
 
-def test_pipeline_five_captions_matches_oracle_flow(hiplib):
-    """The driver's call pattern (stage2_batchtest_rcdms_model.py:364-376): one caption per frame."""
+@pytest.mark.parametrize("hip_vae", [False, True], ids=["stub_vae", "hip_vae"])
+def test_pipeline_five_captions_matches_oracle_flow(hiplib, hip_vae):
+    """The driver's call pattern (stage2_batchtest_rcdms_model.py:364-376): one caption per frame.  With hip_vae the
+    `vae` argument is rcdms_amd.vae.AutoencoderKL (tiny shape), so encode, sampling loop and decode all run on HIP."""
+    from oracle import vae_oracle as VO
+    from rcdms_amd.vae import AutoencoderKL
     from src.pipelines.RCDMs_pipeline import RCDMsPipeline
     dev = "cuda"
     unet = build("unet_tiny")
@@ -70,6 +74,15 @@ def test_pipeline_five_captions_matches_oracle_flow(hiplib):
     local.load_state_dict(sd_l)
     glob.load_state_dict(sd_g)
     text, vae, tok = _Text(), _Vae(), _Tok()
+    if hip_vae:
+        vcfg = VO.tiny_vae_config()
+        shapes = dict(VO.decoder_shapes(vcfg))
+        shapes.update(VO.encoder_shapes(vcfg))
+        sd_vae = synth.procedural_state_dict(shapes, 13)
+        kw = dict(vcfg)
+        kw["norm_num_groups"] = kw.pop("groups")
+        vae = AutoencoderKL(**kw).eval()
+        vae.load_state_dict(sd_vae)
     pipe = RCDMsPipeline(vae=vae, text_encoder=text, tokenizer=tok, unet=unet, local_module=local, global_module=glob,
                          scheduler=DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear")).to(dev)
     H = W = 128
@@ -81,8 +94,10 @@ def test_pipeline_five_captions_matches_oracle_flow(hiplib):
     proj0 = synth.normal_tensor("e2e.proj0", (4, 1, 24), 4)
     lat0 = synth.normal_tensor("e2e.lat", (1, 4, 5, H // 8, W // 8), 5)
     steps, gs = 3, 2.0
+    gen = torch.Generator(device=dev).manual_seed(9)           # consumed by latent_dist.sample only (latents are given)
     out = pipe(caps, src.to(dev), image_embeds_1=img1.to(dev), proj_embeds_0=proj0.to(dev), mask_label=mask_label.to(dev),
-               video_length=5, height=H, width=W, num_inference_steps=steps, guidance_scale=gs, latents=lat0.to(dev)).videos
+               video_length=5, height=H, width=W, num_inference_steps=steps, guidance_scale=gs, latents=lat0.to(dev),
+               generator=gen).videos
     assert tuple(out.shape) == (1, 3, 5, H, W) and torch.isfinite(out).all()
 
     emb = text.emb.weight.detach().cpu()
@@ -92,15 +107,22 @@ def test_pipeline_five_captions_matches_oracle_flow(hiplib):
     f1 = CO.context_stack_forward(sd_l, torch.cat([img1] * 2), te[seen])              # local module on the seen rows
     f0 = CO.context_stack_forward(sd_g, torch.cat([proj0] * 2), te[~seen])            # global module on the rest
     ctx = torch.cat([f1, f0])                                                          # reference order: seen rows first (F5)
-    z = nn.functional.avg_pool2d(src, 8)
-    z = torch.cat([z, z.mean(1, keepdim=True)], dim=1)                                 # (5,4,h,w)
+    if hip_vae:
+        noise = torch.randn(5, 4, H // 8, W // 8, generator=torch.Generator(device=dev).manual_seed(9), device=dev).cpu()
+        with torch.no_grad():
+            z = VO.vae_encode_sample(sd_vae, vcfg, src, noise)
+    else:
+        z = nn.functional.avg_pool2d(src, 8)
+        z = torch.cat([z, z.mean(1, keepdim=True)], dim=1)                             # (5,4,h,w)
     masked = (z.reshape(1, 5, 4, H // 8, W // 8).permute(0, 2, 1, 3, 4) * 0.18215)
     masked = torch.cat([masked] * 2)
     mask5 = ml.view(2, 1, 5, H // 8, W // 8)
     with torch.no_grad():
         lat = O.denoise_loop(sd_unet, cfg, lat0, mask5, masked, ctx, steps, gs)
-    want = vae.decode((lat / 0.18215).permute(0, 2, 1, 3, 4).reshape(5, 4, H // 8, W // 8)).sample
+    zf = (lat / 0.18215).permute(0, 2, 1, 3, 4).reshape(5, 4, H // 8, W // 8)
+    with torch.no_grad():
+        want = VO.vae_decode(sd_vae, vcfg, zf) if hip_vae else vae.decode(zf).sample
     want = (want.reshape(1, 5, 3, H, W).permute(0, 2, 1, 3, 4) / 2 + 0.5).clamp(0, 1)
     r = rel_rms(out.float(), want)
-    print(f"pipeline e2e: rel-RMS {r:.3e}")
+    print(f"pipeline e2e ({'hip' if hip_vae else 'stub'} vae): rel-RMS {r:.3e}")
     assert r <= 2e-2, r
