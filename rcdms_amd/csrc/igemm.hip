@@ -19,9 +19,10 @@
 //     c' ^ ((r>>1)&7); a fragment read of chunk kc of row r reads slot kc ^ ((r>>1)&7).  For the 32x32x16 operand
 //     pattern (lanes 0-31 = rows, lane>>5 = chunk parity) every ds_read_b128 lane group hits 16 distinct slots.
 //   * The WEIGHT tile is the MFMA A operand and the ACTIVATION tile the B operand, so D[channel][pixel]: a lane
-//     owns one pixel and 4 consecutive channels per register quad -> 16-byte staging of the fp32 tile through the
-//     ring stage that was just consumed, then a coalesced 16-byte-per-lane epilogue (bias / per-sample row vector /
-//     residual / GEGLU / scale, fp32, one rounding) while the other stage already receives the next tile.
+//     owns one pixel and 4 consecutive channels per register quad -> the tile is staged through the ring stage
+//     that was just consumed (as f16, 8 bytes per quad; as fp32 for split-K slabs), then a coalesced
+//     16-byte-per-lane epilogue (bias / per-sample row vector / GELU / GEGLU / residual / scale in fp32) while the
+//     other stage already receives the next tile.
 //   tiles <BM, BN, WM x WN waves>: 128x128 (2x2, two blocks per CU) and 256x256 (2x4, one block per CU).
 #include <stdlib.h>
 #include <string.h>
@@ -105,7 +106,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n,
   *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
 }
 
-template <int TAPS, int BM_, int BN_, int WM, int WN, int NSTAGE>
+template <int TAPS, int BM_, int BN_, int WM, int WN, int NSTAGE, bool E16>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmArgs p) {
   constexpr int NW = WM * WN;             // waves
   constexpr int FM = BM_ / WM / 32;       // pixel fragments per wave
@@ -264,7 +265,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     if (s < total) issue_next();
   int c_ks = 0, c_tile = 0;   // k-step / tile being computed
   int c_stage = 0;            // ring slot being computed
-  bool drain = false;         // epilogue stores are in flight: vmcnt counts them too, so wait for everything once
 
   constexpr int PIECES = AI + BI;  // DMA instructions per wave per step
   for (int g = 0; g < total; ++g) {
@@ -272,14 +272,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     // younger steps may still be in flight); the barrier makes everybody's visible and also guarantees every
     // wave is done reading the slot of step g-1, which the issue below refills
     const int younger = min(NSTAGE - 2, total - 1 - g);
-    if (drain || younger <= 0) {
+    if (younger <= 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (NSTAGE >= 4 && younger >= 2) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 4 ? 2 * PIECES : 0) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 3 ? PIECES : 0) : "memory");
     }
-    drain = false;
     __builtin_amdgcn_s_barrier();
     // 8-wave blocks put two waves on every SIMD, released by the same barrier: if both issued their DMA pieces first
     // (each piece stalls the issuing wave for ~100 cycles) the SIMD's matrix pipe would idle through both bursts.
@@ -312,7 +311,137 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     // coalesced 16-byte-per-lane store phase; the DMA of the next tile's first step keeps flowing into the other
     // stage.  Raw s_barrier + lgkmcnt only: a __syncthreads() here would drain that DMA (vmcnt(0)).
     c_ks = 0;
-    {
+    if constexpr (E16) {
+      // ---- f16 staging (every launch without split-K): the accumulators are rounded to f16 (the reference's fp16
+      // Linear / Conv outputs are rounded at the same point, give or take the bias) and staged as [rows][BN] halfs: half the LDS bytes of an fp32 tile through ds_write_b64 (the 13-cycle
+      // ds_write_b128 of the fp32 form made the staging writes cost as much LDS time as a whole K = 320 main loop),
+      // and a 128x128 tile fits the consumed ring slot in ONE pass (two barriers instead of four).  Bias, row vector,
+      // GELU / GEGLU, residual and scale are applied in fp32 on the way out, as in the fp32-staged form.  8-byte pieces are XOR-swizzled by (row & 15): the 16
+      // rows of a ds_write_b64 lane group land in 16 distinct pieces; a 16-byte read finds its two pieces in chunk
+      // c ^ ((row & 15) >> 1), swapped when the row is odd.
+      constexpr int NT = NW * 64;
+      constexpr int RPH = (STAGE_BYTES / (BN_ * 2)) >= BM_ ? BM_ : (STAGE_BYTES / (BN_ * 2)) / 32 * 32;
+      constexpr int NPASS = BM_ / RPH;
+      static_assert(BM_ % RPH == 0 && RPH % 32 == 0, "staging passes must tile the block");
+      f16* sH = (f16*)(smem + e_stage * STAGE_BYTES);
+      constexpr int P_TPR = BN_ / 8, P_RPI = NT / P_TPR, P_ITEMS = RPH / P_RPI;
+      constexpr int G_TPR = BN_ / 16, G_RPI = NT / G_TPR, G_ITEMS = RPH / G_RPI;
+      static_assert(NT % P_TPR == 0 && RPH % P_RPI == 0 && NT % G_TPR == 0 && RPH % G_RPI == 0, "epilogue sweep");
+      const int pc8 = t % P_TPR, pr0 = t / P_TPR;
+      const int pn = cn0 + pc8 * 8;
+      const bool pn_ok = pn < p.N;
+      constexpr bool WHOLE = NPASS * P_ITEMS <= 8;
+      Pack16 resv[WHOLE ? NPASS : 1][P_ITEMS];
+      const bool has_res = !geglu && (p.epi & RCDM_EPI_RESIDUAL);
+      if (WHOLE && !geglu) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+          for (int it = 0; it < P_ITEMS; ++it) {
+            const int m = cm0 + ps * RPH + pr0 + it * P_RPI;
+            resv[WHOLE ? ps : 0][it].u = make_uint4(0, 0, 0, 0);
+            if (has_res && m < p.M && pn_ok) resv[WHOLE ? ps : 0][it].u = *(const uint4*)(p.res + (size_t)m * p.ldr + pn);
+          }
+      }
+      float bb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bb[e] = 0.f;
+      if (!geglu && (p.epi & RCDM_EPI_BIAS) && pn_ok) load8(p.bias + pn, bb);
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        if (!WHOLE && !geglu) {
+#pragma unroll
+          for (int it = 0; it < P_ITEMS; ++it) {
+            const int m = cm0 + ps * RPH + pr0 + it * P_RPI;
+            resv[0][it].u = make_uint4(0, 0, 0, 0);
+            if (has_res && m < p.M && pn_ok) resv[0][it].u = *(const uint4*)(p.res + (size_t)m * p.ldr + pn);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // operand reads (ps = 0) / previous pass's staged reads are complete
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int blk = wm * FM + j;
+          if (blk / (RPH / 32) == ps) {
+            const int prow = (blk % (RPH / 32)) * 32 + lr;
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                union { f16 h[4]; uint2 u; } pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk.h[e] = (f16)acc[i][j][4 * q + e];
+                const int piece = ((wn * FN + i) * 32 + 8 * q + 4 * hi) >> 2;
+                *(uint2*)(sH + prow * BN_ + ((piece ^ (prow & 15)) << 2)) = pk.u;
+              }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int mbase = cm0 + ps * RPH;
+        if (geglu) {
+          const int oc8 = t % G_TPR, r0 = t / G_TPR;
+          const int hc = (oc8 >> 2) * 8 + (oc8 & 3);  // 16-B chunk (8 halfs) of the hidden columns; the gate is 4 chunks on
+          const int n = cn0 + hc * 8;
+          const int oc = geglu_out_col(n);
+          float bh[8], bg[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bh[e] = bg[e] = 0.f;
+          if ((p.epi & RCDM_EPI_BIAS) && n < p.N) {
+            load8(p.bias + n, bh);
+            load8(p.bias + n + 32, bg);
+          }
+#pragma unroll
+          for (int it = 0; it < G_ITEMS; ++it) {
+            const int row = r0 + it * G_RPI;
+            const int m = mbase + row;
+            if (m < p.M && n < p.N) {
+              const int sx = (row & 15) >> 1;
+              Pack16 hh, gg;
+              hh.u = *(const uint4*)(sH + row * BN_ + ((hc ^ sx) << 3));
+              gg.u = *(const uint4*)(sH + row * BN_ + (((hc + 4) ^ sx) << 3));
+              if (row & 1) {
+                hh.u = make_uint4(hh.u.z, hh.u.w, hh.u.x, hh.u.y);
+                gg.u = make_uint4(gg.u.z, gg.u.w, gg.u.x, gg.u.y);
+              }
+              Pack16 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                o.e[e] = (f16)(((float)hh.e[e] + bh[e]) * gelu_f((float)gg.e[e] + bg[e]) * p.out_scale);
+              *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int it = 0; it < P_ITEMS; ++it) {
+            const int row = pr0 + it * P_RPI;
+            const int m = mbase + row;
+            if (m < p.M && pn_ok) {
+              Pack16 hh;
+              hh.u = *(const uint4*)(sH + row * BN_ + ((pc8 ^ ((row & 15) >> 1)) << 3));
+              if (row & 1) hh.u = make_uint4(hh.u.z, hh.u.w, hh.u.x, hh.u.y);
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (float)hh.e[e] + bb[e];
+              if (p.epi & RCDM_EPI_ROWVEC) {
+                float rv[8];
+                load8(p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + pn, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+              }
+              if (p.epi & RCDM_EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+              }
+              Pack16 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + (float)resv[WHOLE ? ps : 0][it].e[e]) * p.out_scale);
+              *(uint4*)(p.out + (size_t)m * p.ldc + pn) = o.u;
+            }
+          }
+        }
+      }
+    } else {
       constexpr int RP = (STAGE_BYTES / (BN_ * 4)) >= 64 ? 64 : 32;   // rows per pass
       constexpr int NPASS = BM_ / RP;
       constexpr int NT = NW * 64;
@@ -459,7 +588,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     ++c_tile;
-    drain = true;
+    // Everything the epilogue left in flight (output stores, and on branches that never consumed them the residual /
+    // bias prefetches) is waited for HERE with the compiler-visible form of s_waitcnt: vmcnt counts the stores too,
+    // so the next step's counted wait could not tell them from DMA pieces anyway, and the builtin lets the
+    // compiler's hazard tracking see that no load is pending into a register the main loop reuses — otherwise it
+    // protects those registers with its own vmcnt(0) inside the k-loop, after every DMA issue.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     if (c_tile < my_tiles) tile_of(c_tile, cm0, cn0);
     if (p.trace) ts_epi += __builtin_amdgcn_s_memtime() - te0;
   }
@@ -616,13 +750,23 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   constexpr int LDS_64 = 2 * (64 + 64) * 128;      // 32 KB
   constexpr int LDS_64D = 4 * (64 + 64) * 128;     // 64 KB  (three steps in flight)
   constexpr int LDS_128x64 = 2 * (128 + 64) * 128; // 48 KB
+  static int epi16_mode = -1;  // RCDM_EPI16=0: keep the fp32-staged epilogue everywhere (A/B switch)
+  if (epi16_mode < 0) {
+    const char* e = getenv("RCDM_EPI16");
+    epi16_mode = e ? atoi(e) : 1;
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2>, LDS_128);
-    set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2>, LDS_256);
-    set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2>, LDS_64);
-    set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4>, LDS_64D);
-    set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2>, LDS_128x64);
+    set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, false>, LDS_128);
+    set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2, false>, LDS_256);
+    set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2, false>, LDS_64);
+    set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4, false>, LDS_64D);
+    set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2, false>, LDS_128x64);
+    set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, true>, LDS_128);
+    set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2, true>, LDS_256);
+    set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2, true>, LDS_64);
+    set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4, true>, LDS_64D);
+    set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2, true>, LDS_128x64);
     attr_set = true;
   }
   if (a.splits > 1) {
@@ -647,13 +791,21 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   if (persist_mode == 0 || (persist_mode == 2 && (a.epi & RCDM_EPI_GEGLU))) gx = ntiles;
   if (gx > ntiles) gx = ntiles;
   dim3 grid(gx, a.splits);
+  // f16-staged epilogue for every direct launch; split-K slabs stay fp32
+  const bool e16 = epi16_mode != 0 && a.splits == 1;
+#define RCDM_IGEMM_LAUNCH(BM, BN, WM, WN, NS, THREADS, LDS)                                                           \
+  do {                                                                                                                \
+    if (e16) hipLaunchKernelGGL((igemm_dma_kernel<TAPS, BM, BN, WM, WN, NS, true>), grid, dim3(THREADS), LDS, stream, a); \
+    else hipLaunchKernelGGL((igemm_dma_kernel<TAPS, BM, BN, WM, WN, NS, false>), grid, dim3(THREADS), LDS, stream, a);    \
+  } while (0)
   switch (variant) {
-    case 2: hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2>), grid, dim3(512), LDS_256, stream, a); break;
-    case 3: hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2>), grid, dim3(256), LDS_64, stream, a); break;
-    case 4: hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4>), grid, dim3(256), LDS_64D, stream, a); break;
-    case 5: hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2>), grid, dim3(256), LDS_128x64, stream, a); break;
-    default: hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2>), grid, dim3(256), LDS_128, stream, a);
+    case 2: RCDM_IGEMM_LAUNCH(256, 256, 2, 4, 2, 512, LDS_256); break;
+    case 3: RCDM_IGEMM_LAUNCH(64, 64, 2, 2, 2, 256, LDS_64); break;
+    case 4: RCDM_IGEMM_LAUNCH(64, 64, 2, 2, 4, 256, LDS_64D); break;
+    case 5: RCDM_IGEMM_LAUNCH(128, 64, 2, 2, 2, 256, LDS_128x64); break;
+    default: RCDM_IGEMM_LAUNCH(128, 128, 2, 2, 2, 256, LDS_128);
   }
+#undef RCDM_IGEMM_LAUNCH
   int rc = rcdm_check_launch();
   if (rc) return rc;
   if (a.splits > 1) {
