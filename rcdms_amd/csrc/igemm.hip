@@ -106,6 +106,29 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n,
   *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
 }
 
+// fma(f16 half `sel` of the dword h, s, c) in fp32: v_fma_mix_f32 converts the f16 source on the fly
+__device__ __forceinline__ float mix_f16_f32(unsigned h, int sel, float s, float c) {
+  float t;
+  if (sel) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(h), "v"(s), "v"(c));
+  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(t) : "v"(h), "v"(s), "v"(c));
+  return t;
+}
+// {f16(fma(r.lo, s, t0)), f16(fma(r.hi, s, t1))}: fp32 fma of the f16 halves of r, one rounding each, packed
+__device__ __forceinline__ unsigned mix_f16_pack(unsigned r, float s, float t0, float t1) {
+  unsigned o;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(o) : "v"(r), "v"(s), "v"(t0), "v"(t1));
+  return o;
+}
+
+// Every load the block has in flight — the next tile's first DMA pieces (issued a k-step and a staging phase ago) and
+// this tile's residual / bias prefetches — is waited for right before the tile's first output store, with the
+// compiler-visible form of s_waitcnt: (a) once stores are in flight vmcnt cannot separate them from DMA pieces, so this
+// is the last point where "operands landed" can be established cheaply; (b) the builtin lets the compiler's hazard
+// tracking see that no load is pending into a register the main loop reuses (prefetches that a branch never consumes
+// would otherwise make it guard those registers with its own vmcnt(0) after every DMA issue in the k-loop).
+#define RCDM_PRE_STORE_WAIT() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0); expcnt / lgkmcnt untouched */
+
 template <int TAPS, int BM_, int BN_, int WM, int WN, int NSTAGE, bool E16>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmArgs p) {
   constexpr int NW = WM * WN;             // waves
@@ -265,6 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     if (s < total) issue_next();
   int c_ks = 0, c_tile = 0;   // k-step / tile being computed
   int c_stage = 0;            // ring slot being computed
+  int post_epi = 0;           // 2: an epilogue just ran (operands of the next step already landed), 1: its stores may be in flight
 
   constexpr int PIECES = AI + BI;  // DMA instructions per wave per step
   for (int g = 0; g < total; ++g) {
@@ -272,12 +296,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     // younger steps may still be in flight); the barrier makes everybody's visible and also guarantees every
     // wave is done reading the slot of step g-1, which the issue below refills
     const int younger = min(NSTAGE - 2, total - 1 - g);
-    if (younger <= 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (NSTAGE >= 4 && younger >= 2) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 4 ? 2 * PIECES : 0) : "memory");
+    if (post_epi == 2) {
+      // first step of a new tile: every DMA piece issued so far was waited for inside the epilogue, BEFORE its output
+      // stores were issued — nothing to wait for here, and the stores' round trip to L2 (vmcnt counts them, and they
+      // retire out of order with loads, so a counted wait cannot skip them) is hidden under this step's MFMAs
+      post_epi = 1;
     } else {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 3 ? PIECES : 0) : "memory");
+      if (post_epi == 1 || younger <= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (post_epi == 1: the epilogue's stores may still be counted)
+      } else if (NSTAGE >= 4 && younger >= 2) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 4 ? 2 * PIECES : 0) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 3 ? PIECES : 0) : "memory");
+      }
+      post_epi = 0;
     }
     __builtin_amdgcn_s_barrier();
     // 8-wave blocks put two waves on every SIMD, released by the same barrier: if both issued their DMA pieces first
@@ -313,12 +345,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     c_ks = 0;
     if constexpr (E16) {
       // ---- f16 staging (every launch without split-K): the accumulators are rounded to f16 (the reference's fp16
-      // Linear / Conv outputs are rounded at the same point, give or take the bias) and staged as [rows][BN] halfs: half the LDS bytes of an fp32 tile through ds_write_b64 (the 13-cycle
-      // ds_write_b128 of the fp32 form made the staging writes cost as much LDS time as a whole K = 320 main loop),
-      // and a 128x128 tile fits the consumed ring slot in ONE pass (two barriers instead of four).  Bias, row vector,
-      // GELU / GEGLU, residual and scale are applied in fp32 on the way out, as in the fp32-staged form.  8-byte pieces are XOR-swizzled by (row & 15): the 16
-      // rows of a ds_write_b64 lane group land in 16 distinct pieces; a 16-byte read finds its two pieces in chunk
-      // c ^ ((row & 15) >> 1), swapped when the row is odd.
+      // Linear / Conv outputs are rounded at the same point, give or take the bias) and staged as [rows][BN] halfs:
+      // half the LDS bytes of an fp32 tile through ds_write_b64, and a 128x128 tile fits the consumed ring slot in ONE
+      // pass (two barriers instead of four).  16-byte chunks are XOR-swizzled by (row >> 1) & 7 (two-way conflicts on
+      // the 16 writes of a wave, none on the reads).  Bias, row vector, GELU / GEGLU, residual and scale are applied
+      // in fp32 on the way out.  The post phase is VALU- and latency-bound (measured: ~3.4 k of a 128x128 tile's ~4.8 k
+      // epilogue ticks), so (a) every global read it needs — bias, the row vector of the (at most two) samples the
+      // tile touches, residual rows — is issued before the staging barriers and covered by ONE wait, so that no
+      // per-item vmcnt wait ends up behind the previous item's store; (b) staged reads of all items are issued
+      // together; (c) out = (h + bias + rowvec + res) * scale runs as v_fma_mix_f32 / v_fma_mixlo|hi_f16 on the f16
+      // inputs directly: 2 instructions per output instead of cvt + add + add + mul + cvt.
       constexpr int NT = NW * 64;
       constexpr int RPH = (STAGE_BYTES / (BN_ * 2)) >= BM_ ? BM_ : (STAGE_BYTES / (BN_ * 2)) / 32 * 32;
       constexpr int NPASS = BM_ / RPH;
@@ -328,11 +364,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
       constexpr int G_TPR = BN_ / 16, G_RPI = NT / G_TPR, G_ITEMS = RPH / G_RPI;
       static_assert(NT % P_TPR == 0 && RPH % P_RPI == 0 && NT % G_TPR == 0 && RPH % G_RPI == 0, "epilogue sweep");
       const int pc8 = t % P_TPR, pr0 = t / P_TPR;
-      const int pn = cn0 + pc8 * 8;
+      const int oc8 = t % G_TPR, gr0 = t / G_TPR;
+      const int hc = (oc8 >> 2) * 8 + (oc8 & 3);  // GEGLU: 16-B chunk (8 halfs) of the hidden columns; the gate is 4 chunks on
+      const int pn = geglu ? cn0 + hc * 8 : cn0 + pc8 * 8;   // first packed column this thread handles
       const bool pn_ok = pn < p.N;
       constexpr bool WHOLE = NPASS * P_ITEMS <= 8;
+      constexpr int RCH = WHOLE ? P_ITEMS : (P_ITEMS < 4 ? P_ITEMS : 4);  // staged reads in flight per thread
       Pack16 resv[WHOLE ? NPASS : 1][P_ITEMS];
       const bool has_res = !geglu && (p.epi & RCDM_EPI_RESIDUAL);
+      const bool has_rv = !geglu && (p.epi & RCDM_EPI_ROWVEC);
+      // per-sample row vector: a tile of BM rows touches at most two samples when rows_per_sample >= BM
+      const bool rv_pair = has_rv && p.rows_per_sample >= BM_;
+      const int smp0 = rv_pair ? cm0 / p.rows_per_sample : 0;
+      const int m_switch = rv_pair ? (smp0 + 1) * p.rows_per_sample : 0x7fffffff;
+      float bA[8], bB[8], rvA[8], rvB[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bA[e] = bB[e] = rvA[e] = rvB[e] = 0.f;
+      if ((p.epi & RCDM_EPI_BIAS) && pn_ok) {
+        load8(p.bias + pn, bA);
+        if (geglu) load8(p.bias + pn + 32, bB);
+      }
+      if (rv_pair && pn_ok) {
+        load8(p.rowvec + (size_t)smp0 * p.ldt + pn, rvA);
+        if (m_switch < p.M && m_switch < cm0 + BM_) load8(p.rowvec + (size_t)(smp0 + 1) * p.ldt + pn, rvB);
+      }
       if (WHOLE && !geglu) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps)
@@ -343,10 +398,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
             if (has_res && m < p.M && pn_ok) resv[WHOLE ? ps : 0][it].u = *(const uint4*)(p.res + (size_t)m * p.ldr + pn);
           }
       }
-      float bb[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bb[e] = 0.f;
-      if (!geglu && (p.epi & RCDM_EPI_BIAS) && pn_ok) load8(p.bias + pn, bb);
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         if (!WHOLE && !geglu) {
@@ -372,72 +423,100 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pk.h[e] = (f16)acc[i][j][4 * q + e];
                 const int piece = ((wn * FN + i) * 32 + 8 * q + 4 * hi) >> 2;
-                *(uint2*)(sH + prow * BN_ + ((piece ^ (prow & 15)) << 2)) = pk.u;
+                *(uint2*)(sH + prow * BN_ + ((piece ^ (((prow >> 1) & 7) << 1)) << 2)) = pk.u;
               }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        RCDM_PRE_STORE_WAIT();
         const int mbase = cm0 + ps * RPH;
+        const float sc = p.out_scale;
         if (geglu) {
-          const int oc8 = t % G_TPR, r0 = t / G_TPR;
-          const int hc = (oc8 >> 2) * 8 + (oc8 & 3);  // 16-B chunk (8 halfs) of the hidden columns; the gate is 4 chunks on
-          const int n = cn0 + hc * 8;
-          const int oc = geglu_out_col(n);
-          float bh[8], bg[8];
+          const int oc = geglu_out_col(pn);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) bh[e] = bg[e] = 0.f;
-          if ((p.epi & RCDM_EPI_BIAS) && n < p.N) {
-            load8(p.bias + n, bh);
-            load8(p.bias + n + 32, bg);
-          }
+          for (int it0 = 0; it0 < G_ITEMS; it0 += RCH) {
+            Pack16 hh[RCH], gg[RCH];
 #pragma unroll
-          for (int it = 0; it < G_ITEMS; ++it) {
-            const int row = r0 + it * G_RPI;
-            const int m = mbase + row;
-            if (m < p.M && n < p.N) {
-              const int sx = (row & 15) >> 1;
-              Pack16 hh, gg;
-              hh.u = *(const uint4*)(sH + row * BN_ + ((hc ^ sx) << 3));
-              gg.u = *(const uint4*)(sH + row * BN_ + (((hc + 4) ^ sx) << 3));
-              if (row & 1) {
-                hh.u = make_uint4(hh.u.z, hh.u.w, hh.u.x, hh.u.y);
-                gg.u = make_uint4(gg.u.z, gg.u.w, gg.u.x, gg.u.y);
+            for (int k = 0; k < RCH; ++k)
+              if (it0 + k < G_ITEMS) {
+                const int row = gr0 + (it0 + k) * G_RPI;
+                const int sx = (row >> 1) & 7;
+                hh[k].u = *(const uint4*)(sH + row * BN_ + ((hc ^ sx) << 3));
+                gg[k].u = *(const uint4*)(sH + row * BN_ + (((hc + 4) ^ sx) << 3));
               }
-              Pack16 o;
 #pragma unroll
-              for (int e = 0; e < 8; ++e)
-                o.e[e] = (f16)(((float)hh.e[e] + bh[e]) * gelu_f((float)gg.e[e] + bg[e]) * p.out_scale);
-              *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
-            }
+            for (int k = 0; k < RCH; ++k)
+              if (it0 + k < G_ITEMS) {
+                const int m = mbase + gr0 + (it0 + k) * G_RPI;
+                if (m < p.M && pn_ok) {
+                  Pack16 o;
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) {
+                    const float hv = mix_f16_f32(hh[k].v[e >> 1], e & 1, 1.0f, bA[e]);
+                    const float gv = mix_f16_f32(gg[k].v[e >> 1], e & 1, 1.0f, bB[e]);
+                    o.e[e] = (f16)(hv * gelu_f(gv) * sc);
+                  }
+                  *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
+                }
+              }
           }
         } else {
+          const bool gelu_on = (p.epi & RCDM_EPI_GELU) != 0;
+          float cA[8], cB[8];  // (bias + row vector) * scale of the tile's first / second sample
 #pragma unroll
-          for (int it = 0; it < P_ITEMS; ++it) {
-            const int row = pr0 + it * P_RPI;
-            const int m = mbase + row;
-            if (m < p.M && pn_ok) {
-              Pack16 hh;
-              hh.u = *(const uint4*)(sH + row * BN_ + ((pc8 ^ ((row & 15) >> 1)) << 3));
-              if (row & 1) hh.u = make_uint4(hh.u.z, hh.u.w, hh.u.x, hh.u.y);
-              float v[8];
+          for (int e = 0; e < 8; ++e) {
+            cA[e] = (bA[e] + rvA[e]) * sc;
+            cB[e] = (bA[e] + rvB[e]) * sc;
+          }
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = (float)hh.e[e] + bb[e];
-              if (p.epi & RCDM_EPI_ROWVEC) {
-                float rv[8];
-                load8(p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + pn, rv);
+          for (int it0 = 0; it0 < P_ITEMS; it0 += RCH) {
+            Pack16 hh[RCH];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            for (int k = 0; k < RCH; ++k)
+              if (it0 + k < P_ITEMS) {
+                const int row = pr0 + (it0 + k) * P_RPI;
+                hh[k].u = *(const uint4*)(sH + row * BN_ + ((pc8 ^ ((row >> 1) & 7)) << 3));
               }
-              if (p.epi & RCDM_EPI_GELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            for (int k = 0; k < RCH; ++k)
+              if (it0 + k < P_ITEMS) {
+                const int it = it0 + k;
+                const int m = mbase + pr0 + it * P_RPI;
+                if (m < p.M && pn_ok) {
+                  const Pack16& rr = resv[WHOLE ? ps : 0][it];
+                  Pack16 o;
+                  if (gelu_on || (has_rv && !rv_pair)) {
+                    // rare forms (stage-1 GELU feed-forward; row vector with fewer rows per sample than the tile):
+                    // plain fp32 arithmetic, row vector read in place
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)hh[k].e[e] + bA[e];
+                    if (has_rv) {
+                      float rv[8];
+                      load8(p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + pn, rv);
+#pragma unroll
+                      for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                    }
+                    if (gelu_on) {
+#pragma unroll
+                      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + (float)rr.e[e]) * sc);
+                  } else {
+                    const bool second = m >= m_switch;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                      const float c0 = second ? cB[2 * d] : cA[2 * d], c1 = second ? cB[2 * d + 1] : cA[2 * d + 1];
+                      const float t0 = mix_f16_f32(hh[k].v[d], 0, sc, c0);
+                      const float t1 = mix_f16_f32(hh[k].v[d], 1, sc, c1);
+                      o.v[d] = mix_f16_pack(rr.v[d], sc, t0, t1);
+                    }
+                  }
+                  *(uint4*)(p.out + (size_t)m * p.ldc + pn) = o.u;
+                }
               }
-              Pack16 o;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + (float)resv[WHOLE ? ps : 0][it].e[e]) * p.out_scale);
-              *(uint4*)(p.out + (size_t)m * p.ldc + pn) = o.u;
-            }
           }
         }
       }
@@ -504,6 +583,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        RCDM_PRE_STORE_WAIT();
         const int mbase = cm0 + ps * RP;
         if (p.splits > 1) {
           constexpr int TPR = BN_ / 8, RPI = NT / TPR, ITEMS = RP / RPI;  // threads per row, rows per sweep
@@ -588,12 +668,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     ++c_tile;
-    // Everything the epilogue left in flight (output stores, and on branches that never consumed them the residual /
-    // bias prefetches) is waited for HERE with the compiler-visible form of s_waitcnt: vmcnt counts the stores too,
-    // so the next step's counted wait could not tell them from DMA pieces anyway, and the builtin lets the
-    // compiler's hazard tracking see that no load is pending into a register the main loop reuses — otherwise it
-    // protects those registers with its own vmcnt(0) inside the k-loop, after every DMA issue.
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    post_epi = 2;
     if (c_tile < my_tiles) tile_of(c_tile, cm0, cn0);
     if (p.trace) ts_epi += __builtin_amdgcn_s_memtime() - te0;
   }
