@@ -856,14 +856,14 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   int gx = num_cus() * kTiles[variant].blocks_per_cu;
   if (a.splits > 1) gx = (gx + a.splits - 1) / a.splits;
   gx = (gx + 7) / 8 * 8;  // keep the b%8 -> XCD pattern aligned across the persistent stride
-  static int persist_mode = -1;  // RCDM_PERSIST: 0 = one tile per block, 1 = always persistent, 2 = auto
+  static int persist_mode = -1;  // RCDM_PERSIST=0: one tile per block (A/B switch); default: persistent blocks
   if (persist_mode < 0) {
     const char* e = getenv("RCDM_PERSIST");
-    persist_mode = e ? atoi(e) : 2;
+    persist_mode = e ? atoi(e) : 1;
   }
-  // a persistent block must drain its epilogue stores (vmcnt counts stores too) before it can trust the next
-  // tile's DMA: with many short tiles per block (GEGLU: 12+ tiles of 5 k-steps) that stall outweighs the prefetch
-  if (persist_mode == 0 || (persist_mode == 2 && (a.epi & RCDM_EPI_GEGLU))) gx = ntiles;
+  // (GEGLU launches used to run one tile per block: a persistent block had to drain its epilogue stores before it
+  // could trust the next tile's DMA.  With the loads waited for BEFORE the stores that stall is gone.)
+  if (persist_mode == 0) gx = ntiles;
   if (gx > ntiles) gx = ntiles;
   dim3 grid(gx, a.splits);
   // f16-staged epilogue for every direct launch; split-K slabs stay fp32
