@@ -521,49 +521,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
         }
       }
     } else {
+      // ---- split-K launches only: the fp32 tile goes to this split's slab (rcdm_*_workspace_bytes), staged through
+      // the consumed ring slot ([RP rows][BN] floats, 16-B chunks XOR-swizzled by row) so that the slab is written
+      // in coalesced 2 x 16-byte pieces per lane; bias / row vector / residual / GEGLU belong to splitk_reduce_kernel
       constexpr int RP = (STAGE_BYTES / (BN_ * 4)) >= 64 ? 64 : 32;   // rows per pass
       constexpr int NPASS = BM_ / RP;
       constexpr int NT = NW * 64;
+      constexpr int TPR = BN_ / 8, RPI = NT / TPR, ITEMS = RP / RPI;  // threads per row, rows per sweep
+      static_assert(NT % TPR == 0 && RP % RPI == 0, "epilogue sweep must tile the pass exactly");
       float* sC = (float*)(smem + e_stage * STAGE_BYTES);
-      // plain (non split-K, non GEGLU) tiles: every global read of the WHOLE tile's epilogue (residual rows,
-      // row-vector slices, bias) is issued here, before the first staging barrier, so the round trips overlap the
-      // LDS staging instead of serialising one dependent load per output chunk
-      constexpr int P_TPR = BN_ / 8, P_RPI = NT / P_TPR, P_ITEMS = RP / P_RPI;
-      static_assert(NT % P_TPR == 0 && RP % P_RPI == 0, "epilogue sweep must tile the pass exactly");
-      const bool plain = p.splits == 1 && !geglu;
-      const int pc8 = t % P_TPR, pr0 = t / P_TPR;
-      const int pn = cn0 + pc8 * 8;
-      const bool pn_ok = pn < p.N;
-      constexpr bool WHOLE = NPASS * P_ITEMS <= 8;  // register budget: 256-row tiles prefetch one pass at a time
-      Pack16 resv[WHOLE ? NPASS : 1][P_ITEMS];
-      float bb[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bb[e] = 0.f;
-      if (plain) {
-        if ((p.epi & RCDM_EPI_BIAS) && pn_ok) load8(p.bias + pn, bb);
-        if (WHOLE) {
-#pragma unroll
-          for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-            for (int it = 0; it < P_ITEMS; ++it) {
-              const int m = cm0 + ps * RP + pr0 + it * P_RPI;
-              resv[WHOLE ? ps : 0][it].u = make_uint4(0, 0, 0, 0);
-              if ((p.epi & RCDM_EPI_RESIDUAL) && m < p.M && pn_ok)
-                resv[WHOLE ? ps : 0][it].u = *(const uint4*)(p.res + (size_t)m * p.ldr + pn);
-            }
-        }
-      }
+      float* dst = p.partial + (size_t)blockIdx.y * p.M * p.N;
+      const int c8 = t % TPR, r0 = t / TPR;
+      const int n = cn0 + c8 * 8;
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
-        if (plain && !WHOLE) {
-#pragma unroll
-          for (int it = 0; it < P_ITEMS; ++it) {
-            const int m = cm0 + ps * RP + pr0 + it * P_RPI;
-            resv[0][it].u = make_uint4(0, 0, 0, 0);
-            if ((p.epi & RCDM_EPI_RESIDUAL) && m < p.M && pn_ok)
-              resv[0][it].u = *(const uint4*)(p.res + (size_t)m * p.ldr + pn);
-          }
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // operand reads (ps = 0) / previous pass's staged reads are complete
 #pragma unroll
@@ -585,78 +556,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
         __builtin_amdgcn_s_barrier();
         RCDM_PRE_STORE_WAIT();
         const int mbase = cm0 + ps * RP;
-        if (p.splits > 1) {
-          constexpr int TPR = BN_ / 8, RPI = NT / TPR, ITEMS = RP / RPI;  // threads per row, rows per sweep
-          static_assert(NT % TPR == 0 && RP % RPI == 0, "epilogue sweep must tile the pass exactly");
-          float* dst = p.partial + (size_t)blockIdx.y * p.M * p.N;
-          const int c8 = t % TPR, r0 = t / TPR;
-          const int n = cn0 + c8 * 8;
 #pragma unroll
-          for (int it = 0; it < ITEMS; ++it) {
-            const int row = r0 + it * RPI;
-            const int m = mbase + row;
-            if (m < p.M && n < p.N) {
-              const f32x4 v0 = *(const f32x4*)(sC + row * BN_ + (((2 * c8) ^ (row & 7)) << 2));
-              const f32x4 v1 = *(const f32x4*)(sC + row * BN_ + (((2 * c8 + 1) ^ (row & 7)) << 2));
-              *(f32x4*)(dst + (size_t)m * p.N + n) = v0;
-              *(f32x4*)(dst + (size_t)m * p.N + n + 4) = v1;
-            }
-          }
-        } else if (geglu) {
-          constexpr int TPR = BN_ / 16, RPI = NT / TPR, ITEMS = RP / RPI;  // 8 outputs per item
-          static_assert(NT % TPR == 0 && RP % RPI == 0, "epilogue sweep must tile the pass exactly");
-          const int oc8 = t % TPR, r0 = t / TPR;
-          const int hch = (oc8 >> 2) * 16 + (oc8 & 3) * 2;  // 16-B chunk of the hidden columns inside the tile
-          const int n = cn0 + hch * 4;
-          float bh[8], bg[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bh[e] = bg[e] = 0.f;
-          if (p.epi & RCDM_EPI_BIAS) {
-            load8(p.bias + n, bh);
-            load8(p.bias + n + 32, bg);
-          }
-          const int oc = geglu_out_col(n);
-#pragma unroll
-          for (int it = 0; it < ITEMS; ++it) {
-            const int row = r0 + it * RPI;
-            const int m = mbase + row;
-            if (m < p.M) {
-              const f32x4 h0 = *(const f32x4*)(sC + row * BN_ + ((hch ^ (row & 7)) << 2));
-              const f32x4 h1 = *(const f32x4*)(sC + row * BN_ + (((hch + 1) ^ (row & 7)) << 2));
-              const f32x4 g0 = *(const f32x4*)(sC + row * BN_ + (((hch + 8) ^ (row & 7)) << 2));
-              const f32x4 g1 = *(const f32x4*)(sC + row * BN_ + (((hch + 9) ^ (row & 7)) << 2));
-              const float hv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-              const float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-              Pack16 o;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o.e[e] = (f16)((hv[e] + bh[e]) * gelu_f(gv[e] + bg[e]) * p.out_scale);
-              *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
-            }
-          }
-        } else {
-#pragma unroll
-          for (int it = 0; it < P_ITEMS; ++it) {
-            const int row = pr0 + it * P_RPI;
-            const int m = mbase + row;
-            if (m < p.M && pn_ok) {
-              const f32x4 v0 = *(const f32x4*)(sC + row * BN_ + (((2 * pc8) ^ (row & 7)) << 2));
-              const f32x4 v1 = *(const f32x4*)(sC + row * BN_ + (((2 * pc8 + 1) ^ (row & 7)) << 2));
-              float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-              if (p.epi & RCDM_EPI_ROWVEC) {  // per-sample vector: L1/L2 resident (a few KB), read in place
-                float rv[8];
-                load8(p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + pn, rv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rv[e];
-              }
-              Pack16 o;
-              if (p.epi & RCDM_EPI_GELU) {  // Linear -> GELU (exact erf form): after bias / row vector, before residual
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e] + bb[e]) - bb[e];
-              }
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + bb[e] + (float)resv[WHOLE ? ps : 0][it].e[e]) * p.out_scale);
-              *(uint4*)(p.out + (size_t)m * p.ldc + pn) = o.u;
-            }
+        for (int it = 0; it < ITEMS; ++it) {
+          const int row = r0 + it * RPI;
+          const int m = mbase + row;
+          if (m < p.M && n < p.N) {
+            const f32x4 v0 = *(const f32x4*)(sC + row * BN_ + (((2 * c8) ^ (row & 7)) << 2));
+            const f32x4 v1 = *(const f32x4*)(sC + row * BN_ + (((2 * c8 + 1) ^ (row & 7)) << 2));
+            *(f32x4*)(dst + (size_t)m * p.N + n) = v0;
+            *(f32x4*)(dst + (size_t)m * p.N + n + 4) = v1;
           }
         }
       }
@@ -825,11 +733,6 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   constexpr int LDS_64 = 2 * (64 + 64) * 128;      // 32 KB
   constexpr int LDS_64D = 4 * (64 + 64) * 128;     // 64 KB  (three steps in flight)
   constexpr int LDS_128x64 = 2 * (128 + 64) * 128; // 48 KB
-  static int epi16_mode = -1;  // RCDM_EPI16=0: keep the fp32-staged epilogue everywhere (A/B switch)
-  if (epi16_mode < 0) {
-    const char* e = getenv("RCDM_EPI16");
-    epi16_mode = e ? atoi(e) : 1;
-  }
   static bool attr_set = false;
   if (!attr_set) {
     set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, false>, LDS_128);
@@ -866,8 +769,8 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   if (persist_mode == 0) gx = ntiles;
   if (gx > ntiles) gx = ntiles;
   dim3 grid(gx, a.splits);
-  // f16-staged epilogue for every direct launch; split-K slabs stay fp32
-  const bool e16 = epi16_mode != 0 && a.splits == 1;
+  // E16 = true: direct launch with the fused epilogue (f16 staging); false: split-K slab writer (fp32 staging)
+  const bool e16 = a.splits == 1;
 #define RCDM_IGEMM_LAUNCH(BM, BN, WM, WN, NS, THREADS, LDS)                                                           \
   do {                                                                                                                \
     if (e16) hipLaunchKernelGGL((igemm_dma_kernel<TAPS, BM, BN, WM, WN, NS, true>), grid, dim3(THREADS), LDS, stream, a); \
