@@ -58,6 +58,8 @@ def ws(nbytes):
     (640, 1280, 1280, 1, 0),         # heuristic split-K
     (130, 72, 200, 1 | 4, 3),        # forced split-K, K tail (200 = 3*64 + 8), N % 128 != 0
     (1024, 960, 320, 0, 1),
+    (260, 64, 64, 1 | 2 | 4, 1),     # row vector with fewer rows per sample (100) than a 128-row tile: in-place reads
+    (400, 320, 128, 1 | 2 | 4, 1),
 ])
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_gemm(hiplib, M, N, K, epi, split, variant):
@@ -67,7 +69,7 @@ def test_gemm(hiplib, M, N, K, epi, split, variant):
     A = h16(torch.randn(M, K, generator=g))
     W = h16(torch.randn(N, K, generator=g) * K ** -0.5)
     bias = torch.randn(N, generator=g)
-    rps = 100
+    rps = 150 if M == 300 else 100   # 150: a 128-row tile straddles two samples (the two-vector prefetch path)
     nsamp = (M + rps - 1) // rps
     rowvec = torch.randn(nsamp, N, generator=g)
     res = h16(torch.randn(M, N, generator=g))
