@@ -62,5 +62,28 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, extra_flags, verbose=False):
+    """A second, differently-flagged build next to the product library (debug / A-B experiments): objects under
+    lib/<name>/, library lib/librcdm_<name>.so; select it at run time with RCDM_LIB=<path>.  Never touches
+    librcdm_hip.so or its stamp."""
+    odir = os.path.join(LIBDIR, name)
+    os.makedirs(odir, exist_ok=True)
+    lib = os.path.join(LIBDIR, f"librcdm_{name}.so")
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(odir, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+        if verbose and out.strip():
+            print(out.decode(errors="replace"), file=sys.stderr)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

@@ -129,6 +129,23 @@ __device__ __forceinline__ unsigned mix_f16_pack(unsigned r, float s, float t0, 
 // would otherwise make it guard those registers with its own vmcnt(0) after every DMA issue in the k-loop).
 #define RCDM_PRE_STORE_WAIT() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0); expcnt / lgkmcnt untouched */
 
+// -DRCDM_TRACE_PHASES (debug builds for tools/trace_phases.py): the trace record grows from 4 to 8 int64 per block and
+// the fused epilogue is stamped after its first barrier, after staging and after the pre-store wait.
+#ifdef RCDM_TRACE_PHASES
+#define RCDM_PHASE_BEGIN() if (p.trace) tq = __builtin_amdgcn_s_memtime()
+#define RCDM_PHASE_STAMP(acc_)                                  \
+  if (p.trace) {                                                \
+    const long long n_ = __builtin_amdgcn_s_memtime();          \
+    acc_ += n_ - tq;                                            \
+    tq = n_;                                                    \
+  }
+constexpr int TRACE_SLOTS = 8;
+#else
+#define RCDM_PHASE_BEGIN()
+#define RCDM_PHASE_STAMP(acc_)
+constexpr int TRACE_SLOTS = 4;
+#endif
+
 template <int TAPS, int BM_, int BN_, int WM, int WN, int NSTAGE, bool E16>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmArgs p) {
   constexpr int NW = WM * WN;             // waves
@@ -263,6 +280,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   long long ts0 = 0, ts_loop = 0, ts_epi = 0;
+  long long ts_a = 0, ts_b = 0, ts_c = 0, tq = 0;  // RCDM_TRACE_PHASES only
   if (p.trace) ts0 = __builtin_amdgcn_s_memtime();
   int cm0, cn0;               // tile being computed
   tile_of(0, cm0, cn0);
@@ -409,7 +427,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RCDM_PHASE_BEGIN();
         __builtin_amdgcn_s_barrier();  // operand reads (ps = 0) / previous pass's staged reads are complete
+        RCDM_PHASE_STAMP(ts_a);
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
           const int blk = wm * FM + j;
@@ -429,7 +449,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        RCDM_PHASE_STAMP(ts_b);
         RCDM_PRE_STORE_WAIT();
+        RCDM_PHASE_STAMP(ts_c);
         const int mbase = cm0 + ps * RPH;
         const float sc = p.out_scale;
         if (geglu) {
@@ -581,13 +603,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     if (p.trace) ts_epi += __builtin_amdgcn_s_memtime() - te0;
   }
   if (p.trace && t == 0) {
-    long long* o = p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    long long* o = p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TRACE_SLOTS;
     o[0] = ts0;
     o[1] = __builtin_amdgcn_s_memtime();
     o[2] = ts_epi;
     o[3] = my_tiles * nkl;
+    if (TRACE_SLOTS == 8) {
+      o[4] = ts_a;
+      o[5] = ts_b;
+      o[6] = ts_c;
+      o[7] = my_tiles;
+    }
   }
-  (void)ts_loop;
+  (void)ts_loop; (void)ts_a; (void)ts_b; (void)ts_c; (void)tq;
 }
 
 // split-K second pass: fixed-order sum of the fp32 slabs + the epilogue (8 output columns per thread).
