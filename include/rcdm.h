@@ -75,6 +75,9 @@ int rcdm_set_igemm_variant(int32_t variant);
 /* debug: when non-NULL, every igemm block writes 4 int64 {start, end (s_memtime ticks), ticks spent in epilogues,
  * k-steps done} at trace[(blockIdx.y*gridDim.x + blockIdx.x)*4]; NULL (default) disables it. */
 int rcdm_debug_set_igemm_trace(void* device_buffer);
+/* roofline calibration: `blocks` x 4 waves each run iters x 4 independent v_mfma_f32_32x32x16_f16 (32768 flop each) and
+ * nothing else; ticks[block] (optional) = s_memtime ticks the first wave spent in its loop.  tools/mfma_peak.py */
+int rcdm_debug_mfma_peak(int32_t blocks, int32_t iters, float* sink, long long* ticks, void* stream);
 int rcdm_gemm(const rcdm_gemm_desc* d, const void* A, const void* W, const float* bias,
               const float* rowvec, const void* residual, void* out, void* workspace,
               size_t workspace_bytes, void* stream);

@@ -6,6 +6,34 @@
 thread_local int g_rcdm_last_hip_error = 0;
 
 namespace {
+// Roofline calibration (tools/mfma_peak.py): nothing but independent v_mfma_f32_32x32x16_f16 chains on every SIMD —
+// the sustained dense-f16 matrix rate this part reaches under full matrix load, and the s_memtime tick rate.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* sink, long long* ticks) {
+  const int lane = threadIdx.x & 63;
+  f16x8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a[e] = (f16)(0.001f * (float)((lane + e) & 7));
+    b[e] = (f16)(0.002f * (float)((lane * 3 + e) & 7));
+  }
+  f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = acc2[e] = acc3[e] = 0.f;
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2, 0, 0, 0);
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc3, 0, 0, 0);
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  float sacc = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sacc += acc0[e] + acc1[e] + acc2[e] + acc3[e];
+  if (sink && sacc == 12345.678f) sink[0] = sacc;  // keep the chains alive
+  if (ticks && threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
 inline int chk(hipError_t e) {
   if (e != hipSuccess) {
     g_rcdm_last_hip_error = (int)e;
@@ -19,6 +47,12 @@ inline int chk(hipError_t e) {
 extern "C" {
 
 int rcdm_version(void) { return RCDM_VERSION; }
+
+int rcdm_debug_mfma_peak(int32_t blocks, int32_t iters, float* sink, long long* ticks, void* stream) {
+  if (blocks <= 0 || iters <= 0) return RCDM_EINVAL;
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink, ticks);
+  return rcdm_check_launch();
+}
 int rcdm_last_hip_error(void) { return g_rcdm_last_hip_error; }
 const char* rcdm_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_rcdm_last_hip_error); }
 

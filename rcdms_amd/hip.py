@@ -65,6 +65,7 @@ SYMBOLS = {
     "rcdm_gemm_workspace_bytes": (_SZ, [C.POINTER(GemmDesc)]),
     "rcdm_set_igemm_variant": (C.c_int, [_I]),
     "rcdm_debug_set_igemm_trace": (C.c_int, [_P]),
+    "rcdm_debug_mfma_peak": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P]),
     "rcdm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_conv3x3_workspace_bytes": (_SZ, [C.POINTER(ConvDesc)]),
     "rcdm_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
