@@ -108,9 +108,11 @@ def bench_conv(variants, rounds):
     hip.set_igemm_variant(-1)
 
 
-def bench_attn(rounds):
+def bench_attn(rounds, only=""):
     for name, batch, heads, L, Lk, d in [("L0 self d=40", 10, 8, 4096, 4096, 40), ("L1 self d=80", 10, 8, 1024, 1024, 80),
                                           ("L2 self d=160", 10, 8, 256, 256, 160), ("L0 cross Lk=85", 10, 8, 4096, 85, 40)]:
+        if only and only not in name:
+            continue
         C = heads * d
         qkv = torch.randn(batch * L, 3 * C, device=DEV).half()
         kv = torch.randn(batch * Lk, 2 * C, device=DEV).half()
@@ -125,6 +127,8 @@ def bench_attn(rounds):
         fl = 4.0 * batch * heads * L * Lk * d
         print(f"attn {name:28s} {fl / 1e9:8.1f} GF | {med:7.1f}us {fl / med / 1e6:6.0f}TF", flush=True)
     for name, b, f, px, heads, d in [("L0 temporal", 2, 5, 4096, 8, 40), ("L1 temporal", 2, 5, 1024, 8, 80)]:
+        if only and only not in name:
+            continue
         C = heads * d
         qkv = torch.randn(b * f * px, 3 * C, device=DEV).half()
         out = torch.empty(b * f * px, C, device=DEV, dtype=torch.float16)
@@ -171,6 +175,6 @@ if __name__ == "__main__":
     if a.what in ("conv", "all"):
         bench_conv(vs, a.rounds)
     if a.what in ("attn", "all"):
-        bench_attn(a.rounds)
+        bench_attn(a.rounds, a.only)
     if a.what in ("norm", "all"):
         bench_norm(a.rounds)
