@@ -253,10 +253,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const f32x2 e2 = __builtin_elementwise_fma((f32x2){sacc[j][f][r], sacc[j][f][r + 1]}, (f32x2){p.c, p.c},
-                                                     (f32x2){-m_new, -m_new});  // v_pk_fma_f32
-          const float p0 = __builtin_amdgcn_exp2f(e2[0]);
-          const float p1 = __builtin_amdgcn_exp2f(e2[1]);
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[j][f][r], p.c, -m_new));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[j][f][r + 1], p.c, -m_new));
           if (!ones_row) lsum += p0 + p1;
           const auto pk = __builtin_amdgcn_cvt_pkrtz(p0, p1);  // v_cvt_pkrtz_f16_f32: two f16 in one VALU op
           pf[j][f * 2 + (r >> 3)][r & 7] = (f16)pk[0];
