@@ -14,7 +14,10 @@ DEV = "cuda"
 
 
 def timeit(fn, rounds=5, inner=10):
-    fn()
+    # warm-up long enough to sit out the clock ramp after an idle gap (the first milliseconds run at ~1.5 GHz,
+    # tools/mfma_peak.py): otherwise whichever variant is timed first looks 10 % slow
+    for _ in range(60):
+        fn()
     torch.cuda.synchronize()
     best = []
     for _ in range(rounds):
