@@ -16,9 +16,12 @@ DEV = "cuda"
 def timeit(fn, rounds=5, inner=10):
     # warm-up long enough to sit out the clock ramp after an idle gap (the first milliseconds run at ~1.5 GHz,
     # tools/mfma_peak.py): otherwise whichever variant is timed first looks 10 % slow
-    for _ in range(60):
-        fn()
-    torch.cuda.synchronize()
+    import time
+    t_end = time.perf_counter() + 0.03
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
     best = []
     for _ in range(rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
