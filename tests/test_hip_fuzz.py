@@ -27,6 +27,7 @@ def test_gemm_random_shapes(hiplib):
         if not geglu:
             epi |= rnd.choice([0, hip.EPI_ROWVEC]) | rnd.choice([0, hip.EPI_RESIDUAL]) | rnd.choice([0, 0, hip.EPI_GELU])
         split = rnd.choice([0, 0, 1, 2, 3])
+        scale = rnd.choice([1.0, 1.0, 0.5, 1 / 1.3])      # 1 / output_scale_factor (resnet.py:210)
         g = torch.Generator().manual_seed(case)
         A = h16(torch.randn(M, K, generator=g))
         W = h16(torch.randn(N, K, generator=g) * K ** -0.5)
@@ -58,8 +59,9 @@ def test_gemm_random_shapes(hiplib):
                 ref = F.gelu(ref)
             if epi & hip.EPI_RESIDUAL:
                 ref = ref + res
+        ref = ref * scale
         rvd = rowvec.to(DEV)
-        d = hip.GemmDesc(M, N, K, lda, ldc, ldr, epi, rps, Nout, 1.0, split)
+        d = hip.GemmDesc(M, N, K, lda, ldc, ldr, epi, rps, Nout, scale, split)
         w = ws(hip.gemm_workspace_bytes(d))
         hip.gemm(d, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), rvd.data_ptr(), Rd.data_ptr(), out.data_ptr(),
                  w.data_ptr(), w.numel())
@@ -67,7 +69,8 @@ def test_gemm_random_shapes(hiplib):
         try:
             close(out[:, :Nout], ref)
         except AssertionError as e:
-            raise AssertionError(f"case {case}: M={M} N={N} K={K} epi={epi} split={split} lda={lda} ldc={ldc}: {e}")
+            raise AssertionError(f"case {case}: M={M} N={N} K={K} epi={epi} split={split} scale={scale:.3f} rps={rps} "
+                                 f"lda={lda} ldc={ldc}: {e}")
         assert torch.isnan(out[:, Nout:].float()).all(), f"case {case}: wrote outside the N columns"
 
 
