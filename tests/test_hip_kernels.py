@@ -207,13 +207,18 @@ def test_groupnorm(hiplib, b, f, H, W, C, cross, silu):
     close(rows_to_5d(y, b, C, f, H, W), ref)
 
 
-@pytest.mark.parametrize("M,C,pe", [(50, 320, False), (40, 640, True), (7, 1280, True), (33, 64, False)])
+@pytest.mark.parametrize("M,C,pe", [(50, 320, False), (40, 640, True), (7, 1280, True), (33, 64, False),
+                                    # production-sized row counts, ragged last wave
+                                    (2051, 320, False), (2400, 320, True), (2049, 640, True), (2050, 1280, False),
+                                    (2400, 1280, True), (2048, 960, False)])
 def test_layernorm(hiplib, M, C, pe):
     from rcdms_amd import hip
     g = torch.Generator().manual_seed(11 + C)
     frames, rpf = 5, 4
-    if pe:
+    if pe and M < 2048:
         M = 2 * frames * rpf
+    if pe and M >= 2048:
+        rpf = 240                       # 2400 rows = 2 samples x 5 frames x 240 rows
     x = h16(torch.randn(M, C, generator=g) * 3 + 1)
     gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
     ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
