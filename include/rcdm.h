@@ -114,7 +114,8 @@ int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, cons
  *   (C/groups, f, H, W) ACROSS frames — at resnet.py:185-186,196,202 and unet.py:455-456
  *   (samples = b, rows_per_sample = f*H*W), and the per-frame 4-D form at attention.py:328 and
  *   motion_module.py:162 (samples = b*f, rows_per_sample = H*W, eps 1e-6, no SiLU).
- *   Two launches: stats (deterministic fixed-order partials, no float atomics) then apply.
+ *   Three launches: stats (deterministic fixed-order partials, no float atomics), finalize, apply; ONE launch when a
+ *   sample has <= 512 rows (the 8x8 / per-frame 16x16 levels): a block owns a whole (sample, group bundle) slab.
  *   C % (2*groups) == 0, C % 8 == 0.  stats workspace: rcdm_groupnorm_workspace_bytes.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {

@@ -5,6 +5,7 @@
 // src/models/resnet.py:185-186,196,202 and unet.py:455-456; the per-frame form
 // attention.py:328 / motion_module.py:162; nn.LayerNorm attention.py:482,502,514,
 // motion_module.py:236,243; PositionalEncoding.forward motion_module.py:265-267.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -155,6 +156,122 @@ __global__ void gn_apply_kernel(const GnArgs p) {
       *(uint4*)(yb + (size_t)(r + u * rstep) * p.ldy) = o.u;
     }
   }
+}
+
+// Single-launch GroupNorm for the smallest levels (16x16 per frame, 8x8: 30 of the 81 GroupNorms of a UNet call).  There the
+// tensor is a few MB, the three-launch form is mostly launch latency (a dependent graph node costs >= 1.6 us even when
+// empty), and one block can own a whole (sample, group-bundle) slab: block (bundle, sample) covers GB consecutive groups
+// = NCHK whole 16-byte chunks of every row (GB chosen so that GB * cg is a multiple of 8), sums x and x^2 over the slab
+// (thread-sequential, then a fixed-order LDS reduction: deterministic), and applies (+SiLU) reading the slab again
+// from L2.  Same arithmetic as one split of gn_stats + gn_finalize + gn_apply.
+struct GnFusedArgs {
+  const f16* x;
+  f16* y;
+  const float* gamma;
+  const float* beta;
+  int P, cg, GB, NCHK, RPB, ldx, ldy, silu;
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void gn_fused_kernel(const GnFusedArgs p) {
+  __shared__ float part[256 * 16];
+  __shared__ float gstat[16 * 2];
+  const int t = threadIdx.x;
+  const int ch = t % p.NCHK, rl = t / p.NCHK;
+  const bool live = rl < p.RPB;
+  const int s = blockIdx.y, c0 = blockIdx.x * p.GB * p.cg;  // first channel of this bundle
+  const f16* xb = p.x + (size_t)s * p.P * p.ldx + c0 + ch * 8;
+  f16* yb = p.y + (size_t)s * p.P * p.ldy + c0 + ch * 8;
+  float sum[8], sq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
+  if (live) {
+    for (int r = rl; r < p.P; r += 4 * p.RPB) {
+      Pack16 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ru = r + u * p.RPB;
+        v[u].u = make_uint4(0, 0, 0, 0);
+        if (ru < p.P) v[u].u = *(const uint4*)(xb + (size_t)ru * p.ldx);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[u].e[e];
+          sum[e] += f;
+          sq[e] += f * f;
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    part[t * 16 + e] = sum[e];
+    part[t * 16 + 8 + e] = sq[e];
+  }
+  __syncthreads();
+  // column sums first (NCHK * 16 values, each over the RPB row-threads, spread over the block), then the few groups
+  __shared__ float colsum[32 * 16];
+  for (int o = t; o < p.NCHK * 16; o += 256) {
+    const int c = o >> 4, k = o & 15;
+    float a = 0.f;
+    for (int r = 0; r < p.RPB; ++r) a += part[(r * p.NCHK + c) * 16 + k];
+    colsum[o] = a;
+  }
+  __syncthreads();
+  if (t < p.GB) {
+    float gs = 0.f, gq = 0.f;
+    for (int c = t * p.cg; c < (t + 1) * p.cg; ++c) {
+      gs += colsum[(c >> 3) * 16 + (c & 7)];
+      gq += colsum[(c >> 3) * 16 + 8 + (c & 7)];
+    }
+    const float n = (float)p.P * (float)p.cg;
+    const float mean = gs / n;
+    float m2 = gq - gs * mean;
+    if (m2 < 0.f) m2 = 0.f;
+    gstat[t * 2] = mean;
+    gstat[t * 2 + 1] = rsqrtf(m2 / n + p.eps);  // biased variance, as torch.nn.GroupNorm
+  }
+  __syncthreads();
+  if (!live) return;
+  float sc[8], sh[8];
+  {
+    const f32x4 g0 = *(const f32x4*)(p.gamma + c0 + ch * 8), g1 = *(const f32x4*)(p.gamma + c0 + ch * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(p.beta + c0 + ch * 8), b1 = *(const f32x4*)(p.beta + c0 + ch * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (ch * 8 + e) / p.cg;
+      const float mean = gstat[g * 2], rstd = gstat[g * 2 + 1];
+      const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
+      sc[e] = rstd * ga;
+      sh[e] = be - mean * rstd * ga;
+    }
+  }
+  for (int r = rl; r < p.P; r += 4 * p.RPB) {
+    Pack16 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r + u * p.RPB < p.P) v[u].u = *(const uint4*)(xb + (size_t)(r + u * p.RPB) * p.ldx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u * p.RPB >= p.P) break;
+      Pack16 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v[u].e[e] * sc[e] + sh[e];
+        if (p.silu) f = silu_f(f);
+        o.e[e] = (f16)f;
+      }
+      *(uint4*)(yb + (size_t)(r + u * p.RPB) * p.ldy) = o.u;
+    }
+  }
+}
+
+// bundle size for the single-launch form: the smallest GB with GB * cg % 8 == 0 that divides the group count; 0 = none
+int gn_fused_bundle(int G, int cg) {
+  for (int gb = 1; gb <= 8; gb <<= 1)
+    if ((gb * cg) % 8 == 0 && G % gb == 0 && gb * cg / 8 <= 32) return gb;
+  return 0;
 }
 
 int gn_plan(const rcdm_groupnorm_desc* d, GnArgs& a) {
@@ -336,6 +453,25 @@ int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float
   if (rc) return rc;
   const size_t need = ((size_t)a.samples * a.splits * a.G * 3 + (size_t)a.samples * a.G * 2) * sizeof(float);
   if (!workspace || workspace_bytes < need) return RCDM_EWORKSPACE;
+  hipStream_t stream0 = (hipStream_t)stream_;
+  {
+    static int fused_mode = -1;  // RCDM_GN_FUSED=0: three-launch form everywhere (A/B switch)
+    if (fused_mode < 0) {
+      const char* e = getenv("RCDM_GN_FUSED");
+      fused_mode = e ? atoi(e) : 1;
+    }
+    const int gb = gn_fused_bundle(a.G, a.cg);
+    // one block per (sample, bundle) pays up to a few hundred rows per sample (measured: 15 -> 9 us at 320 rows, but
+    // 17 -> 22 us at 1280 and 25 -> 64 us at 4096: a single block streams its slab too slowly)
+    if (fused_mode && gb && a.samples * (a.G / gb) >= 48 && a.P <= 512) {
+      GnFusedArgs f;
+      f.x = (const f16*)x; f.y = (f16*)y; f.gamma = gamma; f.beta = beta;
+      f.P = a.P; f.cg = a.cg; f.GB = gb; f.NCHK = gb * a.cg / 8; f.RPB = 256 / f.NCHK;
+      f.ldx = a.ldx; f.ldy = a.ldy; f.silu = a.silu; f.eps = a.eps;
+      hipLaunchKernelGGL(gn_fused_kernel, dim3(a.G / gb, a.samples), dim3(256), 0, stream0, f);
+      return rcdm_check_launch();
+    }
+  }
   a.x = (const f16*)x; a.y = (f16*)y; a.gamma = gamma; a.beta = beta;
   a.partial = (float*)workspace;
   a.stat = a.partial + (size_t)a.samples * a.splits * a.G * 3;

@@ -181,6 +181,13 @@ def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split, variant):
     (1, 5, 16, 16, 64, True, True),     # cg = 2 (tiny config)
     (2, 3, 4, 4, 2560, True, True),     # widest concat input
     (1, 2, 6, 10, 960, False, True),
+    # production shapes of the 8x8 / 16x16 / 32x32 levels: the single-launch form (one block per sample x group bundle)
+    (2, 5, 8, 8, 1280, True, True),     # cg = 40: one group per block
+    (2, 5, 16, 16, 1280, False, False), # 10 samples x 32 blocks
+    (2, 5, 32, 32, 640, False, False),  # cg = 20: two groups per block
+    (2, 5, 16, 16, 2560, True, True),   # cg = 80, 1280 rows per sample
+    (2, 5, 16, 16, 1920, True, True),   # cg = 60: too few blocks for the single-launch form, three-launch path
+    (2, 5, 7, 9, 1280, True, True),     # ragged row count (315 rows per sample)
 ])
 def test_groupnorm(hiplib, b, f, H, W, C, cross, silu):
     from rcdms_amd import hip
