@@ -96,7 +96,7 @@ def cpu_baseline(model, latent, ctx_len, ddim_steps, budget_s=25.0):
             "sample": how + f"; b=2 f=5 L={ctx_len}, fp32 torch CPU restatement, extrapolated x{ddim_steps} steps"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed passes (each = one full T-step story batch)")
@@ -108,14 +108,112 @@ def main():
     ap.add_argument("--guidance", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    a = ap.parse_args()
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="TEST ONLY: exercise the launch / barrier / max-over-ranks harness on CPU (gloo) with a sleep "
+                         "in place of the denoising loop; the printed line is marked data=stub and is not a measurement")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(a, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks ourselves, one process per device, the way the
+    reference's driver does (stage2_batchtest_rcdms_model.py:457-468 spawns one process per GPU) — through
+    torch.distributed.run on 127.0.0.1 so every rank sees RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
+    import socket
+    import subprocess
+    if not a.stub_cpu:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < a.gpus:
+            raise SystemExit(f"bench.py: {a.gpus} ranks requested (--gpus {a.gpus}) but {have} device(s) visible; "
+                             f"one MI355X per rank is required — refusing to report n_gpus={a.gpus} from fewer devices")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def timed_passes(one_pass, steps, dist_mod, sync, device):
+    """The contract's timed region: barrier + sync, EXACTLY `steps` passes, sync + barrier; returns (max over ranks of
+    the wall time, list of every rank's own wall time in rank order)."""
+    if dist_mod is not None:
+        dist_mod.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass()
+    sync()
+    if dist_mod is not None:
+        dist_mod.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    per_rank = [dt]
+    if dist_mod is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(tt) for _ in range(dist_mod.get_world_size())]
+        dist_mod.all_gather(every, tt)
+        per_rank = [float(x.item()) for x in every]
+        dist_mod.all_reduce(tt, op=dist_mod.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, per_rank
+
+
+def traffic_record(S, latent, guidance):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/collect_profiles.sh) — bench.py cannot run
+    the profiler on itself.  Returned with its provenance; dropped (None) when the record was taken from a different
+    kernel library than the one loaded now, so a stale constant is never passed off as this run's traffic."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not (os.path.exists(tpath) and S == 1 and latent == 64 and guidance > 1):
+        return None, None
+    try:
+        with open(tpath) as f:
+            rec = json.load(f)
+        from rcdms_amd import build as rbuild
+        src = f"profiles/hbm_traffic.json@{rec.get('commit', 'unknown')}"
+        if rec.get("csrc_stamp") and rec["csrc_stamp"] != rbuild._stamp():
+            return None, src + " (stale: kernels changed since; not reported)"
+        return float(rec["hbm_bytes_per_unet_step"]), src
+    except Exception:
+        return None, None
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a, argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist_on = world > 1
+    dist = None
+    if a.stub_cpu:
+        dev = torch.device("cpu")
+        if dist_on:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        dt, per_rank = timed_passes(lambda: time.sleep(0.02 * (rank + 1)), a.steps, dist, lambda: None, dev)
+        if rank == 0:
+            print(json.dumps({"metric": "harness self-test (no measurement)", "value": 5 * a.stories * a.steps * world / dt,
+                              "unit": "story-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                              "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "none", "data": "stub",
+                              "per_rank_ms": [round(1e3 * x / a.steps, 3) for x in per_rank]}), flush=True)
+        if dist_on:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
@@ -124,7 +222,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__
-    __graft_entry__.build()
+    if local_rank == 0:
+        __graft_entry__.build()
+    if dist_on:
+        dist.barrier()      # the in-tree library is built once per node, then loaded by every rank
     from rcdms_amd import hip, synth
     from rcdms_amd.sampler import DenoiseLoop
     from rcdms_amd.scheduler import DDIMScheduler
@@ -148,49 +249,30 @@ def main():
 
     # timed region: inputs are re-staged (a few MB H2D) inside load(); the loop itself is K x T graph replays
     ev0, ev1 = hip.Event(), hip.Event()
-    gpu_ms = 0.0
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
+    gpu_ms = [0.0]
+
+    def timed_pass():
         loop.load(story["latents"], story["mask"], story["masked_latents"], story["ctx"])
         sp = loop.prog.stream.cuda_stream
         ev0.record(sp)
         loop.run(use_graph=not a.no_graph)
         ev1.record(sp)
-        gpu_ms += ev0.elapsed_ms(ev1)
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        gpu_ms[0] += ev0.elapsed_ms(ev1)
+
+    dt, per_rank = timed_passes(timed_pass, a.steps, dist if dist_on else None, torch.cuda.synchronize, dev)
 
     frames = 5 * S * a.steps * world
     value = frames / dt
     launches = a.steps * T
-    avg_launch_ms = gpu_ms / launches
+    avg_launch_ms = gpu_ms[0] / launches
     tf_call = ALGO_TFLOP_PER_CALL.get(a.latent)
-    # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/collect_profiles.sh); bench.py cannot run
-    # the profiler on itself, so it reports the committed measurement for this exact workload, else null.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath) and S == 1 and a.latent == 64 and a.guidance > 1:
-        try:
-            with open(tpath) as f:
-                traffic = float(json.load(f)["hbm_bytes_per_unet_step"])
-        except Exception:
-            traffic = None
+    traffic, traffic_src = traffic_record(S, a.latent, a.guidance)
     roof = None
     if tf_call is not None:
         achieved = tf_call * S / (avg_launch_ms * 1e-3)
         roof = {"bound": "mfma", "kernel": "denoise-step graph (UNet b=%d + CFG + DDIM)" % (2 * S if a.guidance > 1 else S),
                 "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches}
 
     out = {
@@ -202,6 +284,7 @@ def main():
                                f"{T}-step DDIM, CFG {a.guidance}, "
                                f"batch={S} story x 5 frames per GPU, ctx {a.ctx_len}x768, random-init 1276.9M-param UNet3D",
                    "stories_per_gpu": S, "latent": a.latent, "ddim_steps": T, "parallelism": f"story-replicas x{world}"},
+        "per_rank_ms": [round(1e3 * x / a.steps, 3) for x in per_rank],
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -270,6 +270,10 @@ int rcdm_pack_conv3x3(const float* w, int32_t c_out, int32_t c_in, int32_t cin_p
 int rcdm_pack_geglu_rows(const float* w, const float* bias, int32_t n_out /*8C*/, int32_t K,
                          void* w_dst, float* bias_dst, void* stream);
 
+/* Mish activation, fp32 elementwise: y = x * tanh(softplus(x)).  Replaces `Mish.forward`
+ * (src/models/resnet.py:215-217); never instantiated by configs/testing.yaml, kept for drop-in completeness. */
+int rcdm_mish(const float* x, float* y, size_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * hipGraph plumbing: capture the ~10^3 launches of one denoising step once, replay per step.
  * ---------------------------------------------------------------------------------------------- */

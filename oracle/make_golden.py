@@ -3,6 +3,7 @@ REFERENCE's own model classes (imported from /root/reference through oracle/ref_
 with procedural name-seeded weights (rcdms_amd/synth.py).  Run in the build container only:
 
     python -m oracle.make_golden [--full] [--only blocks|tiny|ctx|prior|full]   # --full adds the full-width UNet (32x32, 64x64)
+    python -m oracle.make_golden --only loop32|loop64|cfg3     # reference-UNet-driven DDIM trajectories / config-3 story
 
 What is stored: small inputs and the reference outputs (fp32 .npz), plus a digest of the reference's
 state-dict key/shape list so the mirrored classes are checked to have the identical 1286-key layout.
@@ -178,12 +179,92 @@ def prior(which):
              cfg=np.array([layers, heads, hd, E], dtype=np.int64))
 
 
+LOOP_KEEP = {32: list(range(1, 21)), 64: [1, 2, 3, 5, 10, 11, 20, 21, 30, 31, 40, 41, 49, 50]}
+
+
+@torch.no_grad()
+def loop_trajectory(hw, steps):
+    """BASELINE config 1 (32x32 latents, 20 steps) / config 2 (64x64, 50 steps): the REFERENCE UNet3DConditionModel
+    (full width, procedural weights, seed-42 synthetic story) driven through the oracle's restatement of the pipeline
+    loop (RCDMs_pipeline.py:455-503: CFG 2.0, DDIM).  Stores the latents after selected steps, so the HIP loop can be
+    checked per step (x_k -> x_k+1 from a stored x_k) and end to end.  ~12 s (32x32) / ~70 s (64x64) per step here."""
+    from oracle import unet_oracle as O
+    m = ref_scaffold.build_reference_unet()
+    dig = load_procedural(m, seed=0)
+    s = synth.synthetic_story(stories=1, latent_hw=(hw, hw), ctx_len=85, seed=42)
+    keep, out, t0 = set(LOOP_KEEP[hw]), {}, time.time()
+
+    def unet(x, t, ctx):
+        return m(x, torch.tensor(int(t)), encoder_hidden_states=ctx, return_dict=False)[0]
+
+    def cb(i, t, x):
+        if i + 1 in keep:
+            out[f"x{i + 1}"] = x.clone()
+        print("    step %d/%d t=%d  |x| rms %.4f  (%.0f s)" % (i + 1, steps, t, x.pow(2).mean().sqrt(), time.time() - t0),
+              flush=True)
+        if (i + 1) % 10 == 0 or i + 1 == steps:      # checkpoint: a partial file is still a usable fixture
+            save(f"loop_full_{hw}", steps=np.int64(steps), done=np.int64(i + 1), guidance=np.float32(2.0), digest=dig, **out)
+
+    O.denoise_loop(None, None, s["latents"], s["mask"], s["masked_latents"], s["ctx"], steps, 2.0, unet=unet, callback=cb)
+
+
+@torch.no_grad()
+def config3_story():
+    """BASELINE config 3 (FlintstonesSV, L = 91, 4 stories = b 8, 64x64 latents): the reference UNet run on ONE story
+    of the seed-44 four-story batch (its two CFG rows, b = 2) — the batch itself is 4x that and stories are independent."""
+    m = ref_scaffold.build_reference_unet()
+    dig = load_procedural(m, seed=0)
+    s = synth.synthetic_story(stories=4, latent_hw=(64, 64), ctx_len=91, seed=44)
+    i = 2
+    rows = [i, 4 + i]
+    x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1)[rows]
+    ctx = s["ctx"].view(8, 5, 91, 768)[rows].reshape(10, 91, 768)
+    t0 = time.time()
+    y = m(x, torch.tensor(961), encoder_hidden_states=ctx, return_dict=False)[0]
+    print("  reference forward config-3 story %d: %.1f s" % (i, time.time() - t0))
+    save("unet_full_64_cfg3", t=np.int64(961), story=np.int64(i), y=y, digest=dig)
+
+
+def pretrained_2d():
+    """UNet3DConditionModel.from_pretrained_2d (reference unet.py:465-509) run on a tiny SD-style 2-D checkpoint folder
+    (rcdms_amd.synth.write_2d_checkpoint).  Stored: which keys the reference leaves missing / reports unexpected, the
+    config fields it ends up with, and a float64 checksum per loaded tensor group — the mirrored classmethod must agree."""
+    import io
+    import tempfile
+    from contextlib import redirect_stdout
+    ref_unet = ref_scaffold.load_reference_models()
+    kw = ref_scaffold.TESTING_YAML_UNET_KWARGS
+    cfg9 = dict(synth.TINY_2D_CONFIG, in_channels=9)
+    shapes = {k: tuple(v.shape) for k, v in ref_unet.UNet3DConditionModel.from_config(
+        {k: v for k, v in cfg9.items() if not k.endswith("block_types")}, **kw).state_dict().items()}
+    with tempfile.TemporaryDirectory() as d:
+        file_sd = synth.write_2d_checkpoint(os.path.join(d, "unet"), shapes)
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            m = ref_unet.UNet3DConditionModel.from_pretrained_2d(d, subfolder="unet", unet_additional_kwargs=kw)
+    printed = buf.getvalue()
+    sd = m.state_dict()
+    loaded = sorted(k for k in file_sd if k in sd and not k.startswith("conv_in"))
+    missing = sorted(k for k in sd if k not in file_sd or k.startswith("conv_in"))
+    unexpected = sorted(k for k in file_sd if k not in sd and not k.startswith("conv_in"))
+    assert f"### missing keys: {len(missing)}" in printed and f"### unexpected keys: {len(unexpected)}" in printed, printed
+    for k in loaded:
+        assert torch.equal(sd[k], file_sd[k]), k
+    csum = sum(sd[k].double().sum().item() for k in loaded)
+    n_temporal = sum(p.numel() for n, p in m.named_parameters() if "temporal" in n)
+    print(f"  reference: {len(loaded)} loaded, {len(missing)} missing, {len(unexpected)} unexpected; conv_in {tuple(sd['conv_in.weight'].shape)}")
+    save("from_pretrained_2d", missing=np.array("\n".join(missing)), unexpected=np.array("\n".join(unexpected)), n_loaded=np.int64(len(loaded)),
+         checksum=np.float64(csum), n_temporal=np.int64(n_temporal), conv_in_shape=np.array(sd["conv_in.weight"].shape),
+         in_channels=np.int64(m.config.in_channels), down0=np.array(str(m.config.down_block_types[0])),
+         digest=key_digest(sd))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", os.cpu_count())))
     if a.only in ("", "blocks"):
         print("blocks"); blocks()
     if a.only in ("", "tiny"):
@@ -194,3 +275,11 @@ if __name__ == "__main__":
         print("prior transformer"); prior(["prior_tiny"] + (["prior_full"] if a.full else []))
     if a.full or a.only == "full":
         print("full UNet"); full_unet()
+    if a.only == "pretrained2d":
+        print("from_pretrained_2d"); pretrained_2d()
+    if a.only == "loop32":
+        print("config-1 trajectory"); loop_trajectory(32, 20)
+    if a.only == "loop64":
+        print("config-2 trajectory"); loop_trajectory(64, 50)
+    if a.only == "cfg3":
+        print("config-3 story"); config3_story()

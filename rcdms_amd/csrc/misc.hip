@@ -203,6 +203,14 @@ __global__ void pack_f16_kernel(const float* __restrict__ src, f16* __restrict__
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     dst[i] = (f16)src[i];
 }
+// Mish (reference resnet.py:215-217): x * tanh(softplus(x)), fp32 elementwise; softplus with torch's threshold of 20
+__global__ void mish_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    const float sp = v > 20.f ? v : log1pf(__expf(v));
+    y[i] = v * tanhf(sp);
+  }
+}
 // dst[co][tap*cin_pad + ci] = w[co][ci][ky][kx], tap = ky*3+kx
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int c_out, int c_in, int cin_pad, f16* __restrict__ dst) {
   const size_t total = (size_t)c_out * 9 * cin_pad;
@@ -331,6 +339,13 @@ int rcdm_pack_f16(const float* src, void* dst, size_t n, void* stream) {
   if (!src || !dst) return RCDM_EINVAL;
   if (n == 0) return RCDM_OK;
   hipLaunchKernelGGL(pack_f16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (f16*)dst, n);
+  return rcdm_check_launch();
+}
+
+int rcdm_mish(const float* x, float* y, size_t n, void* stream) {
+  if (!x || !y) return RCDM_EINVAL;
+  if (n == 0) return RCDM_OK;
+  hipLaunchKernelGGL(mish_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
   return rcdm_check_launch();
 }
 

@@ -61,14 +61,25 @@ def broadcast_context(ctx, src=0):
 
 
 def gather_stories(latents, dst=0):
-    """Collect every rank's finished latents (S,4,f,h,w) on rank `dst` (concatenated in rank order)."""
+    """Collect every rank's finished latents (S_r,4,f,h,w) on rank `dst`, concatenated in rank order.  Shards may be
+    uneven (split_stories hands the first n % world ranks one story more): shard sizes are exchanged first and every
+    rank pads to the longest, so the one data collective always sees equal shapes; `dst` trims the padding.  On RCCL
+    this is a true gather (ncclGather-style send/recv to one root), not an all_gather to every rank."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return latents
-    world = dist.get_world_size()
-    if dist.get_backend() == "nccl":
-        bufs = [torch.empty_like(latents) for _ in range(world)]
-        dist.all_gather(bufs, latents.contiguous())
-        return torch.cat(bufs) if dist.get_rank() == dst else None
-    bufs = [torch.empty_like(latents) for _ in range(world)] if dist.get_rank() == dst else None
-    dist.gather(latents.contiguous(), bufs, dst=dst)
-    return torch.cat(bufs) if dist.get_rank() == dst else None
+    world, rank = dist.get_world_size(), dist.get_rank()
+    latents = latents.contiguous()
+    n = torch.tensor([latents.shape[0]], dtype=torch.int64, device=latents.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    longest = max(counts)
+    if latents.shape[0] < longest:
+        pad = torch.zeros((longest - latents.shape[0],) + tuple(latents.shape[1:]), dtype=latents.dtype,
+                          device=latents.device)
+        latents = torch.cat([latents, pad])
+    bufs = [torch.empty_like(latents) for _ in range(world)] if rank == dst else None
+    dist.gather(latents, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)])

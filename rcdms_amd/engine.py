@@ -183,11 +183,12 @@ def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out):
 
 
 def emit_flash_attn_masked(plan, q, k, v, batch, heads, Lq, Lk, d_head, out, key_valid, causal):
-    """key_valid: uint8 tensor [batch][Lk] (or None); causal: bool — rcdm_flash_attn_masked."""
+    """key_valid: uint8 tensor [batch][Lk] (or None); causal: bool or a callable evaluated at launch time."""
     d = hip.AttnDesc(batch, heads, Lq, Lk, d_head, q.ld, k.ld, v.ld, out.ld, d_head ** -0.5)
 
     def op():
-        hip.flash_attn_masked(d, q.ptr, k.ptr, v.ptr, key_valid.data_ptr() if key_valid is not None else 0, causal, out.ptr)
+        c = causal() if callable(causal) else causal
+        hip.flash_attn_masked(d, q.ptr, k.ptr, v.ptr, key_valid.data_ptr() if key_valid is not None else 0, bool(c), out.ptr)
     plan.add(op, f"flash_attn_masked B={batch} H={heads} L={Lq} d={d_head}")
     plan.keep += [key_valid]
     plan.n_launch += 1
@@ -271,21 +272,48 @@ def pack_resnet(pk, p):
     return w
 
 
+def pack_attention(pk, a, fused_self):
+    """CrossAttention parameters (attention.py:31-91): fused [q;k;v] for self-attention, q + [k;v] for cross."""
+    w = _NS()
+    has_b = pk.has(a + "to_q.bias")
+    if fused_self:
+        w.qkv = pk.mat_f16(a + "to_q.weight", a + "to_k.weight", a + "to_v.weight")
+        w.qkv_b = torch.cat([pk.vec(a + f"to_{n}.bias") for n in "qkv"]).contiguous() if has_b else None
+    else:
+        w.q = pk.mat_f16(a + "to_q.weight")
+        w.q_b = pk.vec(a + "to_q.bias") if has_b else None
+        w.kv = pk.mat_f16(a + "to_k.weight", a + "to_v.weight")
+        w.kv_b = torch.cat([pk.vec(a + "to_k.bias"), pk.vec(a + "to_v.bias")]).contiguous() if has_b else None
+    w.o, w.o_b = pk.mat_f16(a + "to_out.0.weight"), pk.vec(a + "to_out.0.bias")
+    return w
+
+
+def pack_basic_block(pk, b):
+    """BasicTransformerBlock parameters (attention.py:368-477); attn2 / norm2 are absent in the stage-1 prior's blocks."""
+    C = pk.sd[b + "norm1.weight"].shape[0]
+    w = _NS(C=C, has_cross=pk.has(b + "attn2.to_q.weight"))
+    w.ln = [(pk.vec(b + f"norm{i}.weight"), pk.vec(b + f"norm{i}.bias")) if pk.has(b + f"norm{i}.weight") else None
+            for i in (1, 2, 3)]
+    a1 = pack_attention(pk, b + "attn1.", True)
+    w.qkv1, w.qkv1_b, w.o1, w.o1_b = a1.qkv, a1.qkv_b, a1.o, a1.o_b
+    if w.has_cross:
+        a2 = pack_attention(pk, b + "attn2.", False)
+        w.q2, w.q2_b, w.kv2, w.kv2_b, w.o2, w.o2_b = a2.q, a2.q_b, a2.kv, a2.kv_b, a2.o, a2.o_b
+        w.ctx_dim = pk.sd[b + "attn2.to_k.weight"].shape[1]
+    w.geglu = pk.has(b + "ff.net.0.proj.weight") and pk.sd[b + "ff.net.0.proj.weight"].shape[0] == 8 * C
+    if w.geglu:
+        w.ff1, w.ff1_b = pk.geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias")
+    else:
+        w.ff1, w.ff1_b = pk.mat_f16(b + "ff.net.0.proj.weight"), pk.vec(b + "ff.net.0.proj.bias")
+    w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
+    return w
+
+
 def pack_transformer(pk, p):
-    C = pk.sd[p + "norm.weight"].shape[0]
-    b = p + "transformer_blocks.0."
-    w = _NS(C=C, ctx_dim=pk.sd[b + "attn2.to_k.weight"].shape[1])
+    w = pack_basic_block(pk, p + "transformer_blocks.0.")
     w.gn_g, w.gn_b = pk.vec(p + "norm.weight"), pk.vec(p + "norm.bias")
     w.proj_in, w.proj_in_b = pk.mat_f16(p + "proj_in.weight"), pk.vec(p + "proj_in.bias")
     w.proj_out, w.proj_out_b = pk.mat_f16(p + "proj_out.weight"), pk.vec(p + "proj_out.bias")
-    w.ln = [(pk.vec(b + f"norm{i}.weight"), pk.vec(b + f"norm{i}.bias")) for i in (1, 2, 3)]
-    w.qkv1 = pk.mat_f16(b + "attn1.to_q.weight", b + "attn1.to_k.weight", b + "attn1.to_v.weight")
-    w.o1, w.o1_b = pk.mat_f16(b + "attn1.to_out.0.weight"), pk.vec(b + "attn1.to_out.0.bias")
-    w.q2 = pk.mat_f16(b + "attn2.to_q.weight")
-    w.kv2 = pk.mat_f16(b + "attn2.to_k.weight", b + "attn2.to_v.weight")
-    w.o2, w.o2_b = pk.mat_f16(b + "attn2.to_out.0.weight"), pk.vec(b + "attn2.to_out.0.bias")
-    w.ff1, w.ff1_b = pk.geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias")
-    w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
     return w
 
 
@@ -352,35 +380,49 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C):
     emit_gemm(plan, gg, ff2, C, 4 * C, tok, bias=ff2_b, residual=tok)
 
 
+def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0):
+    """BasicTransformerBlock.forward (src/models/attention.py:479-526) in place on tok [n_seq*Lq][C]:
+    h += attn1(LN1(h)); h += attn2(LN2(h), ctx); h += FF(LN3(h)).  ctx_kv: Rows [n_seq*L][2C] = [K | V] of the context."""
+    C, M = w.C, n_seq * Lq
+    d_head = C // heads
+    # self-attention over the Lq tokens of each sequence
+    emit_layernorm(plan, tok, w.ln[0][0], w.ln[0][1], a)
+    qkv = plan.rows("qkv", M, 3 * C)
+    emit_gemm(plan, a, w.qkv1, 3 * C, C, qkv, bias=w.qkv1_b)
+    ao = plan.rows("attn_out", M, C)
+    emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), n_seq, heads, Lq, Lq, d_head, ao)
+    emit_gemm(plan, ao, w.o1, C, C, tok, bias=w.o1_b, residual=tok)
+    if w.has_cross:
+        # cross-attention over the L context rows of that sequence
+        emit_layernorm(plan, tok, w.ln[1][0], w.ln[1][1], a)
+        qc = plan.rows("qkv", M, C)
+        emit_gemm(plan, a, w.q2, C, C, qc, bias=w.q2_b)
+        emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), n_seq, heads, Lq, L, d_head, ao)
+        emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok)
+    if w.geglu:
+        emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, M, C)
+    else:   # FeedForward("gelu"): Linear -> exact GELU -> Linear (stage-1 prior blocks)
+        emit_layernorm(plan, tok, w.ln[2][0], w.ln[2][1], a)
+        hid = plan.rows("geglu", M, 4 * C)
+        emit_gemm(plan, a, w.ff1, 4 * C, C, hid, bias=w.ff1_b, gelu=True)
+        emit_gemm(plan, hid, w.ff2, C, 4 * C, tok, bias=w.ff2_b, residual=tok)
+
+
 def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32):
     """Transformer3DModel.forward + BasicTransformerBlock.forward (src/models/attention.py:318-365,479-526).
     ctx_kv: Rows [n_img*L][2C] = [K | V] projections of the context for this site (computed per context)."""
     g, C = geo, w.C
-    d_head = C // heads
     a = plan.rows("norm", g.M, C)
     emit_groupnorm(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, False, a, groups)
     tok = plan.rows("tok", g.M, C)
     emit_gemm(plan, a, w.proj_in, C, C, tok, bias=w.proj_in_b)
-    # self-attention over the hw patches of each frame
-    emit_layernorm(plan, tok, w.ln[0][0], w.ln[0][1], a)
-    qkv = plan.rows("qkv", g.M, 3 * C)
-    emit_gemm(plan, a, w.qkv1, 3 * C, C, qkv)
-    ao = plan.rows("attn_out", g.M, C)
-    emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), g.n_img, heads, g.hw, g.hw, d_head, ao)
-    emit_gemm(plan, ao, w.o1, C, C, tok, bias=w.o1_b, residual=tok)
-    # cross-attention over the L context rows of that frame
-    emit_layernorm(plan, tok, w.ln[1][0], w.ln[1][1], a)
-    qc = plan.rows("qkv", g.M, C)
-    emit_gemm(plan, a, w.q2, C, C, qc)
-    emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), g.n_img, heads, g.hw, L, d_head, ao)
-    emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok)
-    emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, g.M, C)
+    emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L)
     emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
 
 
 def emit_ctx_kv(plan, w, ctx16, ctx_kv):
     """[K | V] = ctx [to_k; to_v]^T  (CrossAttention.forward attention.py:139-141) — context only."""
-    emit_gemm(plan, ctx16, w.kv2, 2 * w.C, w.ctx_dim, ctx_kv)
+    emit_gemm(plan, ctx16, w.kv2, 2 * w.C, w.ctx_dim, ctx_kv, bias=getattr(w, "kv2_b", None))
 
 
 def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
@@ -622,11 +664,17 @@ class UNetProgram:
         self.n_sites = site[0]
 
     # ---- context ---------------------------------------------------------------------------------
-    def set_context(self, ctx):
+    def set_context(self, ctx, force=False):
         """ctx (b*f, L, D) any float dtype/device.  Recomputes the 16 [K|V] projections only if the
         context changed (the reference recomputes them every step, attention.py:139-141)."""
-        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape), ctx.dtype, ctx.device)
-        if key == self.ctx_key:
+        # The cache key is the caller's tensor OBJECT (held strongly, so its storage cannot be recycled for another
+        # context while it is the key) plus its version counter; an address/_version pair alone identifies a transient
+        # allocation, not its contents.  Tensors without a version counter (inference mode) are never cached.
+        try:
+            ver = ctx._version
+        except RuntimeError:
+            ver = None
+        if not force and ver is not None and self.ctx_key is not None and self.ctx_key[0] is ctx and self.ctx_key[1] == ver:
             return
         n_img = self.b * self.f
         if tuple(ctx.shape) != (n_img, self.L, self.cfg["cross_attention_dim"]):
@@ -640,7 +688,7 @@ class UNetProgram:
             self._ctx_plan.run()
         cur.wait_stream(self.stream)
         src.record_stream(self.stream)
-        self.ctx_key = key
+        self.ctx_key = (ctx, ver) if ver is not None else None
 
     # ---- execution -------------------------------------------------------------------------------
     def run_body(self):
@@ -723,6 +771,77 @@ def _as_rows(t, M, C, ld):
     return Rows(_Holder(t), 0, M, C, ld)
 
 
+def _tokens16(x):
+    """(B, L, C) any float dtype -> f16 rows [B*L][C] on the device."""
+    x32 = x.detach().to(torch.float32).contiguous()
+    rows = torch.empty(x32.shape[0] * x32.shape[1], x32.shape[2], dtype=torch.float16, device=x32.device)
+    hip.pack_f16(x32.data_ptr(), rows.data_ptr(), x32.numel())
+    return rows, x32
+
+
+def run_tokens(kind, sd, x, ctx=None, heads=8):
+    """Run a token-level reference module on the HIP path.  x (B, Lq, C) -> (B, Lq, C) fp32.
+      "attention": CrossAttention.forward (attention.py:113-168) — self-attention when ctx is None;
+      "block":     BasicTransformerBlock.forward (attention.py:479-526), ctx (B, L, D) when the block has attn2."""
+    if not x.is_cuda:
+        raise hip.RcdmError("rcdms_amd runs on MI355X only: input tensor is not on a CUDA/HIP device (no CPU fallback)")
+    if x.dim() != 3:
+        raise ValueError(f"expected (batch, tokens, channels), got {tuple(x.shape)}")
+    device = x.device
+    B, Lq, C = x.shape
+    plan = Plan(device)
+    pk = Packer(sd, device)
+    xr_t, x32 = _tokens16(x)
+    M = B * Lq
+    tok = _as_rows(xr_t, M, C, C)
+    c16 = None
+    if ctx is not None:
+        if ctx.dim() != 3 or ctx.shape[0] != B:
+            raise ValueError(f"encoder_hidden_states must be (batch, L, D) with batch {B}, got {tuple(ctx.shape)}")
+        c_t, c32 = _tokens16(ctx.to(device))
+        L = ctx.shape[1]
+        c16 = _as_rows(c_t, B * L, ctx.shape[2], ctx.shape[2])
+    if kind == "attention":
+        inner = sd["to_q.weight"].shape[0]
+        d_head = inner // heads
+        out = plan.rows("out", M, sd["to_out.0.weight"].shape[0], unique=True)
+        ao = plan.rows("attn_out", M, inner)
+        if c16 is None:
+            w = pack_attention(pk, "", True)
+            qkv = plan.rows("qkv", M, 3 * inner)
+            emit_gemm(plan, tok, w.qkv, 3 * inner, C, qkv, bias=w.qkv_b)
+            emit_flash_attn(plan, qkv.cols(0, inner), qkv.cols(inner, inner), qkv.cols(2 * inner, inner), B, heads, Lq, Lq,
+                            d_head, ao)
+        else:
+            w = pack_attention(pk, "", False)
+            q = plan.rows("qkv", M, inner)
+            emit_gemm(plan, tok, w.q, inner, C, q, bias=w.q_b)
+            kv = plan.rows("ctx_kv", c16.M, 2 * inner, unique=True)
+            emit_gemm(plan, c16, w.kv, 2 * inner, c16.C, kv, bias=w.kv_b)
+            emit_flash_attn(plan, q, kv.cols(0, inner), kv.cols(inner, inner), B, heads, Lq, ctx.shape[1], d_head, ao)
+        emit_gemm(plan, ao, w.o, out.C, inner, out, bias=w.o_b)
+        res_rows = out
+    elif kind == "block":
+        w = pack_basic_block(pk, "")
+        kv = None
+        if w.has_cross:
+            if c16 is None:
+                raise ValueError("this BasicTransformerBlock has a cross-attention: encoder_hidden_states is required")
+            kv = plan.rows("ctx_kv", c16.M, 2 * C, unique=True)
+            emit_ctx_kv(plan, w, c16, kv)
+        a = plan.rows("norm", M, C)
+        emit_basic_block(plan, w, tok, B, Lq, heads, a, kv, ctx.shape[1] if ctx is not None else 0)
+        res_rows = tok
+    else:
+        raise ValueError(kind)
+    pk.done()
+    plan.materialize()
+    plan.run()
+    torch.cuda.synchronize(device)
+    t16 = res_rows.buf.t.view(torch.float16)[:M * res_rows.ld].view(M, res_rows.ld)[:, :res_rows.C]
+    return t16.float().reshape(B, Lq, res_rows.C)
+
+
 def run_block(kind, sd, x, device=None, **kw):
     """Run ONE reference block on the HIP path: kind in {"resnet","transformer","motion","down","up","conv"}.
     x (b,C,f,H,W); returns (b,C',f,H',W') fp32.  Used by the mirrored nn.Module classes' forward()."""
@@ -765,6 +884,10 @@ def run_block(kind, sd, x, device=None, **kw):
         w = pack_motion(pk, "", kw["n_attn"])
         out = plan.rows("out", geo.M, c, unique=True)
         emit_motion(plan, w, xr, geo, kw["heads"], out, groups)
+        oc, oh, ow = c, H, W
+    elif kind == "groupnorm":   # InflatedGroupNorm.forward (resnet.py:21-29): nn.GroupNorm applied frame by frame
+        out = plan.rows("out", geo.M, c, unique=True)
+        emit_groupnorm(plan, xr, geo.n_img, geo.hw, pk.vec("weight"), pk.vec("bias"), kw["eps"], False, out, groups)
         oc, oh, ow = c, H, W
     elif kind in ("down", "up", "conv"):
         cw = sd["weight"] if kind == "conv" else sd["conv.weight"]

@@ -87,6 +87,7 @@ SYMBOLS = {
     "rcdm_load_timestep": (C.c_int, [_P, _P, _P, _I, _P]),
     "rcdm_advance_step": (C.c_int, [_P, _P]),
     "rcdm_pack_f16": (C.c_int, [_P, _P, _SZ, _P]),
+    "rcdm_mish": (C.c_int, [_P, _P, _SZ, _P]),
     "rcdm_pack_conv3x3": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "rcdm_pack_geglu_rows": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
     "rcdm_graph_begin_capture": (C.c_int, [_P]),
@@ -248,6 +249,10 @@ def advance_step(step, stream=None):
 
 def pack_f16(src, dst, n, stream=None):
     _check(load().rcdm_pack_f16(src, dst, n, stream_ptr() if stream is None else stream), "rcdm_pack_f16")
+
+
+def mish(x, y, n, stream=None):
+    _check(load().rcdm_mish(x, y, n, stream_ptr() if stream is None else stream), "rcdm_mish")
 
 
 def pack_conv3x3(w, c_out, c_in, cin_pad, dst, stream=None):

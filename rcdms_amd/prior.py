@@ -94,7 +94,7 @@ class PriorProgram:
             emit_gemm(plan, a, blk.qkv, 3 * C, C, qkv, bias=blk.qkv_b)
             ao = plan.rows("attn_out", M, C)
             emit_flash_attn_masked(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), B, self.heads, L, L, self.dh,
-                                   ao, self.kvalid, True)
+                                   ao, self.kvalid, lambda: self.causal)
             emit_gemm(plan, ao, blk.o, C, C, tok, bias=blk.o_b, residual=tok)
             emit_layernorm(plan, tok, blk.ln3[0], blk.ln3[1], a)
             hid = plan.rows("geglu", M, 4 * C)
@@ -109,6 +109,7 @@ class PriorProgram:
         plan.materialize()
         self._d_in = hip.GemmDesc(B, C, self.E, self.E, L * C, 0, hip.EPI_BIAS, 1, 0, 1.0, 1)
         self.ctx_key = None
+        self.causal = True
 
     # ---- per story ------------------------------------------------------------------------------------------------
     def _linear(self, x32, w16, bias):
@@ -139,6 +140,10 @@ class PriorProgram:
         seq[:, T + 3:T + 5] = 0.0
         self.base.copy_(seq.reshape(B * L, C).to(torch.float16))
         self.kvalid.fill_(1)
+        # the reference adds the causal mask only together with a padding mask (myprior_transformer.py:389-393); with
+        # attention_mask=None its blocks attend bidirectionally.  The flag is read at launch time, so a captured graph
+        # must be re-captured when it changes (PriorLoop checks `causal` against what it captured).
+        self.causal = attention_mask is not None
         if attention_mask is not None:
             self.kvalid[:, :T] = (to(attention_mask).reshape(B, T) != 0).to(torch.uint8)
         self.ctx_key = True

@@ -24,6 +24,11 @@ class DenoiseLoop:
         cfg = getattr(scheduler, "config", {})
         if getattr(cfg, "prediction_type", "epsilon") != "epsilon":
             raise NotImplementedError("only epsilon prediction")
+        # the fused rcdm_cfg_ddim_step is DDIM eq. (12) with eta = 0 and no clipping / thresholding — what the reference
+        # pipeline configures (RCDMs_pipeline.py:84-109 forces clip_sample False); anything else must not run silently
+        if getattr(cfg, "clip_sample", False) or getattr(cfg, "thresholding", False):
+            raise NotImplementedError("DenoiseLoop: clip_sample / thresholding are not built into the fused DDIM step "
+                                      "(the reference pipeline sets clip_sample=False)")
         scheduler.set_timesteps(self.T, device=None)
         ts = torch.as_tensor(scheduler.timesteps).to("cpu", torch.int64)
         self.timesteps = ts
@@ -75,13 +80,18 @@ class DenoiseLoop:
         self.lat.copy_(latents.to(self.device, torch.float32) * self.init_noise_sigma)
         self.mask.copy_(mask.to(self.device, torch.float32))
         self.masked.copy_(masked_latents.to(self.device, torch.float32))
-        self.prog.set_context(ctx)
+        self.prog.set_context(ctx, force=True)   # ~3 MB + 16 small GEMMs per story: never trust a cache here
         self.step_dev.zero_()
         torch.cuda.current_stream(self.device).synchronize()
 
-    def run(self, callback=None, callback_steps=1, use_graph=True):
-        """Run all T steps on the program's stream; returns the final latents (S,4,f,H,W) fp32 (device)."""
+    def run(self, callback=None, callback_steps=1, use_graph=True, start=0, steps=None):
+        """Run steps [start, start + steps) of the T-step schedule (default: all T) on the program's stream from the
+        latents staged by load(); returns the latents (S,4,f,H,W) fp32 (device) after the last step run."""
         p = self.prog
+        start = int(start)
+        stop = self.T if steps is None else start + int(steps)
+        if not (0 <= start < stop <= self.T):
+            raise ValueError(f"steps [{start}, {stop}) outside the {self.T}-step schedule")
         cur = torch.cuda.current_stream(self.device)
         p.stream.wait_stream(cur)
         with torch.cuda.stream(p.stream):
@@ -93,7 +103,8 @@ class DenoiseLoop:
                 self.step_dev.zero_()
                 p.stream.synchronize()
                 self.graph = p.capture(pre=self._pre, post=self._post)
-            for i in range(self.T):
+            self.step_dev.fill_(start)
+            for i in range(start, stop):
                 if use_graph:
                     self.graph.launch()
                 else:
@@ -144,6 +155,7 @@ class PriorLoop:
                                                     self.step_dev.data_ptr()),
                         lambda: hip.advance_step(self.step_dev.data_ptr())])
         self.graph = None
+        self._graph_causal = None
 
     def load(self, latents, proj_embedding, encoder_hidden_states, proj_embedding1, mask_label, attention_mask,
              noise=None, generator=None):
@@ -167,7 +179,10 @@ class PriorLoop:
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
+            if use_graph and self.graph is not None and self._graph_causal != self.prog.causal:
+                self.graph = None             # the mask mode is baked into the captured launches
             if use_graph and self.graph is None:
+                self._graph_causal = self.prog.causal
                 lat0 = self.lat.clone()
                 self._one_step_eager()        # load every kernel once outside capture, then restore the state
                 self.lat.copy_(lat0)

@@ -99,6 +99,7 @@ class DDIMScheduler:
         x0 = (sample - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
         if c.clip_sample:
             x0 = x0.clamp(-1.0, 1.0)
+        if use_clipped_model_output:   # diffusers 0.24: epsilon is re-derived from the clipped x0 only on request
             model_output = (sample - a_t ** 0.5 * x0) / (1 - a_t) ** 0.5
         prev_sample = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * model_output
         if not return_dict:

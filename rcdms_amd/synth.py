@@ -82,3 +82,36 @@ def synthetic_story(stories=1, frames=5, latent_hw=(64, 64), ctx_len=85, ctx_dim
     mask[:, :, 0] = 1.0
     ctx = torch.randn(reps * stories * frames, ctx_len, ctx_dim, generator=g)
     return dict(latents=lat, mask=torch.cat([mask] * reps), masked_latents=torch.cat([ml] * reps), ctx=ctx)
+
+
+# ---- a tiny SD-1.5-style 2-D UNet checkpoint directory (config.json + diffusion_pytorch_model.bin) -----------------
+TINY_2D_CONFIG = {   # the fields of runwayml/stable-diffusion-v1-5 unet/config.json, narrowed to width 32
+    "_class_name": "UNet2DConditionModel", "_diffusers_version": "0.6.0", "act_fn": "silu", "attention_head_dim": 8,
+    "block_out_channels": [32, 64, 64, 64], "center_input_sample": False, "cross_attention_dim": 64,
+    "down_block_types": ["CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"],
+    "downsample_padding": 1, "flip_sin_to_cos": True, "freq_shift": 0, "in_channels": 4, "layers_per_block": 2,
+    "mid_block_scale_factor": 1, "norm_eps": 1e-05, "norm_num_groups": 32, "out_channels": 4, "sample_size": 8,
+    "up_block_types": ["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"]}
+
+
+def write_2d_checkpoint(dirpath, shapes_3d, seed=11, extra_key="unexpected_2d_only.weight"):
+    """Write <dirpath>/config.json and <dirpath>/diffusion_pytorch_model.bin the way an SD-1.5 `unet/` folder looks to
+    UNet3DConditionModel.from_pretrained_2d (reference unet.py:465-509): the 2-D model has no motion-module tensors, a
+    4-channel conv_in, and here one extra tensor the 3-D model does not know.  shapes_3d: name -> shape of the inflated
+    3-D model's state dict (either side's: the layouts are digest-checked identical).  Values are name-seeded."""
+    import json
+    import os
+    os.makedirs(dirpath, exist_ok=True)
+    with open(os.path.join(dirpath, "config.json"), "w") as f:
+        json.dump(TINY_2D_CONFIG, f)
+    sd = {}
+    for k, shp in shapes_3d.items():
+        if "motion_modules" in k:
+            continue
+        shp = tuple(shp)
+        if k == "conv_in.weight":
+            shp = (shp[0], 4) + shp[2:]
+        sd[k] = procedural_tensor(k, shp, seed)
+    sd[extra_key] = procedural_tensor(extra_key, (3, 5), seed)
+    torch.save(sd, os.path.join(dirpath, "diffusion_pytorch_model.bin"))
+    return sd

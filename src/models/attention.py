@@ -71,7 +71,14 @@ class CrossAttention(nn.Module):
         self._slice_size = slice_size
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
-        raise NotImplementedError("CrossAttention runs fused inside Transformer3DModel / the motion module on HIP")
+        """attention.py:113-168: to_q / to_k / to_v -> softmax(scale QK^T) V -> to_out, on (batch, tokens, channels).
+        Standalone HIP dispatch (three GEMMs around the flash kernel); inside Transformer3DModel the same kernels run
+        from the block's fused plan."""
+        if attention_mask is not None:
+            raise NotImplementedError("CrossAttention.forward: attention_mask is never passed by the stage-2 pipeline; the "
+                                      "stage-1 prior's causal / padding masks run through rcdm_flash_attn_masked in its plan")
+        return engine.run_tokens("attention", self.state_dict(), hidden_states, ctx=encoder_hidden_states,
+                                 heads=self.heads).to(hidden_states.dtype)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -96,8 +103,13 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
         self.norm3 = nn.LayerNorm(dim)
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("BasicTransformerBlock runs fused inside Transformer3DModel on the HIP path")
+    def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, attention_mask=None, video_length=None):
+        """attention.py:479-526: h += attn1(norm1(h)); h += attn2(norm2(h), ctx); h += ff(norm3(h)) on
+        (batch*frames, tokens, channels).  Standalone HIP dispatch of the block's launch list."""
+        if attention_mask is not None:
+            raise NotImplementedError("BasicTransformerBlock.forward: attention_mask is never passed by the stage-2 pipeline")
+        return engine.run_tokens("block", self.state_dict(), hidden_states, ctx=encoder_hidden_states,
+                                 heads=self.attn1.heads).to(hidden_states.dtype)
 
 
 class Transformer3DModel(nn.Module):

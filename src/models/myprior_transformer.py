@@ -100,10 +100,19 @@ class MyPriorTransformer(nn.Module):
         B, T = hidden_states.shape[0], encoder_hidden_states.shape[1]
         prog = self._program(B, T)
         ctx = (proj_embedding, encoder_hidden_states, proj_embedding1, mask_label, attention_mask)
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else None for t in ctx)
-        if prog.ctx_key != key:
+        # cache on tensor identity (objects held strongly, so their storage cannot be recycled) + version counters
+        def _ver(t):
+            try:
+                return t._version
+            except RuntimeError:      # inference-mode tensors carry no version counter: never cached
+                return None
+        vers = tuple(_ver(t) if torch.is_tensor(t) else -1 for t in ctx)
+        old = prog.ctx_key
+        same = (old is not None and None not in vers and len(old[0]) == len(ctx)
+                and all(a is b for a, b in zip(old[0], ctx)) and old[1] == vers)
+        if not same:
             prog.set_context(*ctx)
-            prog.ctx_key = key
+            prog.ctx_key = (ctx, vers)
         out = prog.forward(hidden_states, timestep).to(hidden_states.dtype)
         return PriorTransformerOutput(predicted_image_embedding=out) if return_dict else (out,)
 

@@ -25,10 +25,14 @@ class InflatedConv3d(nn.Conv2d):
 
 
 class InflatedGroupNorm(nn.GroupNorm):
-    """Per-frame GroupNorm (reference resnet.py:21-29).  Only meaningful inside a block on the HIP path."""
+    """Per-frame GroupNorm (reference resnet.py:21-29: "b c f h w -> (b f) c h w", nn.GroupNorm, back)."""
 
     def forward(self, x):
-        raise NotImplementedError("InflatedGroupNorm runs fused inside its owning block on the HIP path")
+        if x.dim() != 5:
+            raise ValueError(f"InflatedGroupNorm expects (b, c, f, h, w), got {tuple(x.shape)}")
+        if not self.affine:
+            raise NotImplementedError("InflatedGroupNorm without affine parameters has no HIP path")
+        return engine.run_block("groupnorm", _sd(self), x, eps=self.eps, groups=self.num_groups).to(x.dtype)
 
 
 class Upsample3D(nn.Module):
@@ -95,5 +99,15 @@ class ResnetBlock3D(nn.Module):
 
 
 class Mish(nn.Module):
+    """resnet.py:215-217: x * tanh(softplus(x)).  Never instantiated by configs/testing.yaml (non_linearity "silu");
+    kept callable for drop-in completeness through the elementwise HIP kernel rcdm_mish."""
+
     def forward(self, hidden_states):
-        raise NotImplementedError("Mish is never used by the stage-2 configuration")
+        from rcdms_amd import hip
+        if not hidden_states.is_cuda:
+            raise hip.RcdmError("rcdms_amd runs on MI355X only: input tensor is not on a CUDA/HIP device (no CPU fallback)")
+        x = hidden_states.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(x)
+        hip.mish(x.data_ptr(), out.data_ptr(), x.numel())
+        torch.cuda.current_stream(x.device).synchronize()
+        return out.to(hidden_states.dtype)

@@ -105,6 +105,7 @@ class UNet3DConditionModel(nn.Module):
         self.config = _Config({n: frame.f_locals[n] for n in names})
         self._internal_dict = self.config
         self._programs = {}
+        self._weights_gen = 0   # bumped whenever parameters may have changed: cached launch plans / loops key on it
 
         if class_embed_type is not None or num_class_embeds is not None:
             raise NotImplementedError("class embeddings are not used by the stage-2 UNet")
@@ -227,12 +228,18 @@ class UNet3DConditionModel(nn.Module):
             module.gradient_checkpointing = value
 
     # ---- weights changed -> drop cached launch plans -------------------------------------------------------
-    def load_state_dict(self, *args, **kwargs):
+    MAX_LIVE_PLANS = 3   # geometries kept packed at once (2.55 GB of f16 weights + ~3.5 GB of buffers each)
+
+    def _invalidate(self):
         self._programs = {}
+        self._weights_gen = getattr(self, "_weights_gen", 0) + 1
+
+    def load_state_dict(self, *args, **kwargs):
+        self._invalidate()
         return super().load_state_dict(*args, **kwargs)
 
     def _apply(self, fn, *args, **kwargs):
-        self._programs = {}
+        self._invalidate()
         return super()._apply(fn, *args, **kwargs)
 
     def engine_config(self):
@@ -263,9 +270,13 @@ class UNet3DConditionModel(nn.Module):
         key = (b, frames, H, W, L, str(dev))
         prog = self._programs.get(key)
         if prog is None:
+            while len(self._programs) >= self.MAX_LIVE_PLANS:      # least recently used geometry goes first
+                self._programs.pop(next(iter(self._programs)))
             with torch.no_grad():
                 prog = engine.UNetProgram(self.engine_config(), self.state_dict(), b, frames, H, W, L, dev)
-            self._programs = {key: prog}  # one live plan: a new geometry replaces the old buffers
+        else:
+            self._programs.pop(key)
+        self._programs[key] = prog                                  # (re)insert as most recently used
         return prog
 
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
@@ -277,7 +288,18 @@ class UNet3DConditionModel(nn.Module):
             raise ValueError(f"sample must be (b, c, f, h, w), got {tuple(sample.shape)}")
         if self.config.center_input_sample:
             sample = 2 * sample - 1.0
-        b, _, f, H, W = sample.shape
+        b, c_in, f, H, W = sample.shape
+        if c_in != self.config.in_channels:
+            raise ValueError(f"sample has {c_in} channels, conv_in expects {self.config.in_channels} "
+                             f"(latents + mask + masked latents, RCDMs_pipeline.py:482)")
+        mk = dict(self.config.motion_module_kwargs or {})
+        if self.config.use_motion_module and mk.get("temporal_position_encoding", False):
+            max_len = mk.get("temporal_position_encoding_max_len", 24)
+            if f > max_len:
+                raise ValueError(f"{f} frames exceed the temporal position-encoding table (max_len {max_len})")
+        if encoder_hidden_states.dim() != 3 or encoder_hidden_states.shape[0] != b * f:
+            raise ValueError(f"encoder_hidden_states must be (b*f, L, D) = ({b * f}, L, {self.config.cross_attention_dim}), "
+                             f"got {tuple(encoder_hidden_states.shape)}")
         t = timestep
         if torch.is_tensor(t) and t.numel() > 1:
             t = t.reshape(-1)

@@ -234,12 +234,12 @@ class RCDMsPipeline:
         """latents (S,4,f,h,w); mask (R*S,1,f,h,w); masked_latents (R*S,4,f,h,w); context (R*S*f, L, D)."""
         S, _, f, h, w = latents.shape
         key = (S, f, h, w, context.shape[1], float(guidance_scale), int(num_inference_steps), id(self.scheduler),
-               id(self.unet), len(self.unet._programs))
+               id(self.unet), self.unet._weights_gen)
         if self._loop is None or self._loop_key != key:
             self._loop = DenoiseLoop(self.unet, S, f, h, w, context.shape[1], guidance_scale, self.scheduler,
                                      num_inference_steps)
             self._loop_key = (S, f, h, w, context.shape[1], float(guidance_scale), int(num_inference_steps),
-                              id(self.scheduler), id(self.unet), len(self.unet._programs))
+                              id(self.scheduler), id(self.unet), self.unet._weights_gen)
         self._loop.load(latents, mask, masked_latents, context)
         return self._loop.run(callback=callback, callback_steps=callback_steps)
 

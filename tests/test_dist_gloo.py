@@ -36,10 +36,7 @@ def _worker(rank, world, port, q):
         broadcast_context(ctx, src=0)
         shard = split_stories(5, world)[rank]
         lat = torch.stack([torch.full((4, 5, 2, 2), float(i)) for i in shard]) if shard else torch.zeros(0, 4, 5, 2, 2)
-        # gather needs equal shapes: pad shards to the longest one (what a driver would do for ragged shards)
-        longest = max(len(s) for s in split_stories(5, world))
-        pad = torch.full((longest - lat.shape[0], 4, 5, 2, 2), -1.0)
-        out = gather_stories(torch.cat([lat, pad]), dst=0)
+        out = gather_stories(lat, dst=0)                     # ragged shards (3 + 2 stories): sizes are exchanged inside
         q.put((rank, digest, ctx.sum().item(), None if out is None else out[:, 0, 0, 0, 0].tolist()))
     finally:
         dist.destroy_process_group()
@@ -59,4 +56,46 @@ def test_broadcast_and_gather_world2():
     (r0, d0, c0, g0), (r1, d1, c1, g1) = res
     assert d0 == d1, "weights differ after broadcast"
     assert c0 == 0.0 and c1 == 0.0
-    assert g0 == [0.0, 1.0, 2.0, 3.0, 4.0, -1.0] and g1 is None
+    assert g0 == [0.0, 1.0, 2.0, 3.0, 4.0] and g1 is None
+
+
+# ---- bench.py's own launch / barrier / max-over-ranks path (the form the driver calls: `python bench.py --gpus N`) ----
+
+def _run_bench(*args, timeout=180):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=root)
+
+
+def test_bench_gpus_flag_spawns_ranks_world2():
+    """`bench.py --gpus 2` with no launcher self-spawns two ranks; the stub pass sleeps 20 ms on rank 0 and 40 ms on
+    rank 1, so the reported time must be the SLOWER rank's (max over ranks) and n_gpus must be 2."""
+    import json
+    r = _run_bench("--gpus", "2", "--stub-cpu", "--steps", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["data"] == "stub" and len(out["per_rank_ms"]) == 2
+    assert out["ms_per_step"] >= 39.0, out      # rank 1's 40 ms, not rank 0's 20 ms
+    assert abs(out["value"] - 5 * 3 * 2 / (out["ms_per_step"] * 3e-3)) < 1e-4 * out["value"]
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """On a box with fewer devices than --gpus the bench must fail loudly, never print n_gpus from fewer devices."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run_bench("--gpus", str(max(have, 1) + 1))
+    assert r.returncode != 0
+    assert "ranks requested" in (r.stderr + r.stdout) and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_bench_world_size_mismatch_is_an_error():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-cpu"], capture_output=True,
+                       text=True, timeout=120, env=env, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

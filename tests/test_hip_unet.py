@@ -1,9 +1,11 @@
 """GPU parity tests, block and model level: the mirrored `src.models` classes running on the HIP path
 (through the C-ABI library) against the golden vectors minted from the REFERENCE's classes on CPU fp32.
 
-Stated fp16 tolerance (f16 storage between kernels, fp32 accumulation; the reference is fp32 end to end):
-  single block : rel-RMS <= 3e-3, max-abs <= 1.5e-2 * max|ref|
-  whole UNet   : rel-RMS <= 1e-2, max-abs <= 5e-2 * max|ref|   (~60 residual layers of f16 rounding)"""
+Stated fp16 tolerance (f16 storage between kernels, fp32 accumulation; the reference is fp32 end to end), set at
+<= 2x what is measured on MI355X so that a regression which doubles the error fails:
+  single block        : rel-RMS <= 1.5e-3, max-abs <= 6e-3 * max|ref|     (measured 4-7e-4 / <= 3e-3)
+  whole UNet, one call: rel-RMS <= 4e-3,   max-abs <= 6e-3 * max|ref|     (measured 2.0e-3 / 2.4e-3 at full width, 64x64)
+  sampling loop       : per DDIM step rel-RMS <= 4e-3 of the step's output; end to end see LOOP_TOL below."""
 import os
 
 import numpy as np
@@ -56,7 +58,7 @@ def test_block_vs_reference(hiplib, kind):
             y = m(x, None, None)
         else:
             y = m(x)
-    check(y, g["y"], 3e-3, 1.5e-2, kind)
+    check(y, g["y"], 1.5e-3, 6e-3, kind)
 
 
 def test_cpu_tensor_raises(hiplib):
@@ -75,7 +77,7 @@ def test_tiny_unet_vs_reference(hiplib, name):
     with torch.no_grad():
         y = m(g["x"].to(DEV), t.to(DEV), g["ctx"].to(DEV), return_dict=False)[0]
         y2 = m(g["x"].to(DEV), t.to(DEV), g["ctx"].to(DEV))          # second call: hipGraph replay
-    check(y, g["y"], 1e-2, 5e-2, name + " eager")
+    check(y, g["y"], 4e-3, 8e-3, name + " eager")
     assert torch.is_tensor(y2)
     assert torch.equal(y, y2), "graph replay differs from the eager launch sequence"
 
@@ -95,7 +97,7 @@ def test_full_unet_vs_reference(full_unet, hw):
     x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1).to(DEV)
     with torch.no_grad():
         y = full_unet(x, torch.tensor(g["t"]), s["ctx"].to(DEV), return_dict=False)[0]
-    check(y, g["y"], 1e-2, 5e-2, f"unet_full_{hw}")
+    check(y, g["y"], 4e-3, 6e-3, f"unet_full_{hw}")
 
 
 def test_full_unet_batch_independence_and_determinism(full_unet):
@@ -114,24 +116,82 @@ def test_full_unet_batch_independence_and_determinism(full_unet):
     assert not torch.equal(y0[1], y2[1])
 
 
-def test_full_unet_flintstones_batch4(full_unet):
-    """BASELINE config 3 shape: 4 stories with CFG (b = 8) and the FlintstonesSV context length L = 91, full width,
-    32x32 latents.  Stories are independent, so every story of the batch must reproduce the same story run
-    as a batch of one — not bitwise (tile shapes and split-K plans depend on M) but well inside the f16 tolerance."""
-    s = synth.synthetic_story(stories=4, latent_hw=(32, 32), ctx_len=91, seed=44)
+@pytest.mark.parametrize("hw", [32, 64])
+def test_full_unet_flintstones_batch4(full_unet, hw):
+    """BASELINE config 3: FlintstonesSV, 4 stories with CFG (b = 8), context length L = 91, full width — at the stated
+    512x512 size (64x64 latents) and at 32x32.  (a) story 2 of the batch against the REFERENCE's fp32 output for that story
+    (tests/golden/unet_full_64_cfg3.npz: the reference UNet run on the story's two CFG rows; stories are independent,
+    SURVEY §8e); (b) every checked story of the batch reproduces the same story run as a batch of one — not bitwise
+    (tile shapes and split-K plans depend on M) but well inside the f16 tolerance."""
+    s = synth.synthetic_story(stories=4, latent_hw=(hw, hw), ctx_len=91, seed=44)
     lat2 = torch.cat([s["latents"]] * 2)                                    # [uncond x4 | cond x4]
     x = torch.cat([lat2, s["mask"], s["masked_latents"]], dim=1).to(DEV)
     ctx = s["ctx"].to(DEV)                                                  # (2*4*5, 91, 768)
     with torch.no_grad():
         y = full_unet(x, 961, ctx).clone().float().cpu()
-    assert y.shape == (8, 4, 5, 32, 32) and torch.isfinite(y).all()
+    assert y.shape == (8, 4, 5, hw, hw) and torch.isfinite(y).all()
+    if hw == 64:
+        g = gold("unet_full_64_cfg3")
+        i = int(g["story"])
+        assert int(g["t"]) == 961
+        check(y[[i, 4 + i]], g["y"], 4e-3, 6e-3, f"config-3 story {i} of the b=8 batch vs the reference")
     for i in (0, 3):
         rows = [i, 4 + i]                                                   # the two CFG halves of story i
         xi = x[rows].contiguous()
         ci = ctx.view(8, 5, 91, 768)[rows].reshape(10, 91, 768).contiguous()
         with torch.no_grad():
             yi = full_unet(xi, 961, ci).clone().float().cpu()
-        check(y[rows], yi, 3e-3, 2e-2, f"story {i} of the batch vs alone")
+        check(y[rows], yi, 2e-3, 1e-2, f"story {i} of the batch vs alone ({hw}x{hw})")
+
+
+# ---- the sampling loop at the REAL width against reference-UNet-driven trajectories (RCDMs_pipeline.py:455-503) ------
+# golden: oracle/make_golden.py --only loop32|loop64 — the reference UNet3DConditionModel (1276.9 M parameters,
+# procedural weights, seed-42 story) inside the oracle's CFG + DDIM loop, latents stored after selected steps.
+# Random-init weights make eps non-noise-like, so |x| grows ~20x over the trajectory and the recurrence amplifies
+# differences; the tolerances below are <= 2x the drift measured on MI355X (DESIGN.md §5).
+LOOP_TOL = {32: dict(step=4e-3, end=2.5e-2), 64: dict(step=4e-3, end=4e-2)}
+
+
+def _full_loop(full_unet, hw, steps):
+    from rcdms_amd.sampler import DenoiseLoop
+    from rcdms_amd.scheduler import DDIMScheduler
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    return DenoiseLoop(full_unet, 1, 5, hw, hw, 85, 2.0, sched, steps)
+
+
+@pytest.mark.parametrize("hw,steps", [(32, 20), (64, 50)])
+def test_full_width_loop_vs_reference_trajectory(full_unet, hw, steps):
+    """BASELINE config 1 (256x256, 20 steps) and config 2 (512x512, 50 steps): T replays of the captured 1.28 G-parameter
+    step graph vs the reference-driven trajectory.  (a) end to end from x_0: the drift after every stored step is
+    printed, the final one bounded; (b) per step: restart from a stored reference x_k, run ONE step, compare with the
+    stored x_k+1 (isolates the single-step f16 error from the recurrence's amplification)."""
+    g = gold(f"loop_full_{hw}")
+    done = int(g["done"])
+    assert int(g["steps"]) == steps and float(g["guidance"]) == 2.0
+    s = synth.synthetic_story(stories=1, latent_hw=(hw, hw), ctx_len=85, seed=42)
+    loop = _full_loop(full_unet, hw, steps)
+    loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+    drift = {}
+
+    def cb(i, t, lat):
+        k = f"x{i + 1}"
+        if k in g:
+            drift[i + 1] = rel_rms(lat.detach().float().cpu(), g[k])
+    loop.run(callback=cb, steps=done)
+    print(f"loop {hw}x{hw}: drift vs reference trajectory (rel-RMS) " + " ".join(f"{k}:{v:.2e}" for k, v in drift.items()))
+    last = max(drift)
+    assert last == done
+    assert drift[last] <= LOOP_TOL[hw]["end"], f"end-to-end drift {drift[last]:.3e} after {last} steps"
+    assert drift[1] <= LOOP_TOL[hw]["step"], f"first step off by {drift[1]:.3e}"
+    # per-step: from the reference's own x_k
+    pairs = [k for k in range(1, done) if f"x{k}" in g and f"x{k + 1}" in g]
+    assert pairs
+    for k in pairs[:: max(1, len(pairs) // 5)]:
+        loop.load(g[f"x{k}"], s["mask"], s["masked_latents"], s["ctx"])
+        out = loop.run(start=k, steps=1).clone()
+        r = rel_rms(out.float().cpu(), g[f"x{k + 1}"])
+        print(f"  one step from reference x{k}: rel-RMS {r:.2e}")
+        assert r <= LOOP_TOL[hw]["step"], f"step {k}->{k + 1}: {r:.3e}"
 
 
 def _tiny_story(S, cfg=True, seed=3):
@@ -157,7 +217,7 @@ def test_denoise_loop_vs_oracle(hiplib, guidance):
     assert seen == [(0, 751), (1, 501), (2, 251), (3, 1)]
     with torch.no_grad():
         ref = O.denoise_loop(sd, cfg, s["latents"], s["mask"], s["masked_latents"], s["ctx"], 4, guidance)
-    check(out, ref, 1e-2, 5e-2, f"4-step loop gs={guidance}")
+    check(out, ref, 4e-3, 1e-2, f"4-step loop gs={guidance}")
     # replaying the same loop object is bit-reproducible, and eager == graph
     loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
     out2 = loop.run().clone()
@@ -184,4 +244,4 @@ def test_story_batch_equals_single_stories(hiplib):
         loop1 = DenoiseLoop(m, 1, 5, 16, 16, 13, 2.0, mk(), 3)
         loop1.load(s2["latents"][i:i + 1], mask, ml, ctx)
         one = loop1.run().clone().cpu()
-        check(both[i:i + 1], one, 3e-3, 1.5e-2, f"story {i} of a batch of 2 vs alone")
+        check(both[i:i + 1], one, 2e-3, 1e-2, f"story {i} of a batch of 2 vs alone")

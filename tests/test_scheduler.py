@@ -60,3 +60,31 @@ def test_timestep_embedding_known_answers():
     w159 = math.exp(-math.log(10000.0) * 159 / 160)
     assert abs(e[0, 159].item() - math.cos(981.0 * w159)) < 1e-5
     assert torch.allclose(e[1, :160], torch.ones(160)) and torch.allclose(e[1, 160:], torch.zeros(160))
+
+
+def test_clip_sample_follows_diffusers_semantics():
+    """diffusers 0.24 DDIMScheduler.step: clip_sample clamps the predicted x0; epsilon is re-derived from the clipped x0
+    ONLY with use_clipped_model_output=True.  Closed form on a sample whose x0 leaves [-1, 1]."""
+    s = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1)   # clip_sample=True
+    s.set_timesteps(50)
+    ac = s.alphas_cumprod.double()
+    a_t, a_p = ac[981], ac[961]
+    x, eps = torch.full((1, 2), 0.9), torch.full((1, 2), -0.3)
+    x0 = (0.9 - math.sqrt(1 - a_t) * -0.3) / math.sqrt(a_t)
+    assert x0 > 1.0
+    keep = s.step(eps, 981, x).prev_sample[0, 0].item()
+    assert abs(keep - (math.sqrt(a_p) * 1.0 + math.sqrt(1 - a_p) * -0.3)) < 1e-5            # clipped x0, ORIGINAL eps
+    redo = s.step(eps, 981, x, use_clipped_model_output=True).prev_sample[0, 0].item()
+    eps2 = (0.9 - math.sqrt(a_t) * 1.0) / math.sqrt(1 - a_t)
+    assert abs(redo - (math.sqrt(a_p) * 1.0 + math.sqrt(1 - a_p) * eps2)) < 1e-5
+
+
+def test_geglu_half_order_known_answer_oracle():
+    """GEGLU = hidden * gelu(gate) with hidden the FIRST half of the projection (diffusers 0.24 `chunk(2, dim=-1)`):
+    identity hidden rows, zero gate rows with bias 10 (gelu(10) == 10 in fp32), identity output layer -> 10 x."""
+    C = 6
+    sd = {"net.0.proj.weight": torch.cat([torch.eye(C), torch.zeros(C, C)]),
+          "net.0.proj.bias": torch.cat([torch.zeros(C), torch.full((C,), 10.0)]),
+          "net.2.weight": torch.eye(C), "net.2.bias": torch.zeros(C)}
+    x = torch.randn(4, C, generator=torch.Generator().manual_seed(0))
+    assert torch.allclose(O.feed_forward_geglu(sd, "", x), 10.0 * x, rtol=1e-6, atol=1e-6)
