@@ -86,7 +86,8 @@ def test_geglu_half_order_known_answer(hiplib):
     b[C:] = 10.0
     wd = torch.empty(2 * C, C, dtype=torch.float16, device=DEV)
     bd = torch.empty(2 * C, dtype=torch.float32, device=DEV)
-    hip.pack_geglu_rows(w.to(DEV).data_ptr(), b.to(DEV).data_ptr(), 2 * C, C, wd.data_ptr(), bd.data_ptr())
+    w_dev, b_dev = w.to(DEV), b.to(DEV)            # keep the device copies alive across the asynchronous pack
+    hip.pack_geglu_rows(w_dev.data_ptr(), b_dev.data_ptr(), 2 * C, C, wd.data_ptr(), bd.data_ptr())
     x = synth.normal_tensor("geglu.x", (M, C), 8).to(DEV).half()
     out = torch.empty(M, C, dtype=torch.float16, device=DEV)
     d = hip.GemmDesc(M, 2 * C, C, C, C, 0, hip.EPI_BIAS | hip.EPI_GEGLU, 1, 0, 1.0, 1)

@@ -5,7 +5,8 @@ Stated fp16 tolerance (f16 storage between kernels, fp32 accumulation; the refer
 <= 2x what is measured on MI355X so that a regression which doubles the error fails:
   single block        : rel-RMS <= 1.5e-3, max-abs <= 6e-3 * max|ref|     (measured 4-7e-4 / <= 3e-3)
   whole UNet, one call: rel-RMS <= 4e-3,   max-abs <= 6e-3 * max|ref|     (measured 2.0e-3 / 2.4e-3 at full width, 64x64)
-  sampling loop       : per DDIM step rel-RMS <= 4e-3 of the step's output; end to end see LOOP_TOL below."""
+  same story, different batch: rel-RMS <= 4e-3 (two f16 evaluations with different tile / split-K plans differ by 1.9-2.0e-3)
+  sampling loop       : see LOOP_TOL below (measured 8.2e-4 after 20 steps at full width)."""
 import os
 
 import numpy as np
@@ -141,15 +142,16 @@ def test_full_unet_flintstones_batch4(full_unet, hw):
         ci = ctx.view(8, 5, 91, 768)[rows].reshape(10, 91, 768).contiguous()
         with torch.no_grad():
             yi = full_unet(xi, 961, ci).clone().float().cpu()
-        check(y[rows], yi, 2e-3, 1e-2, f"story {i} of the batch vs alone ({hw}x{hw})")
+        check(y[rows], yi, 4e-3, 6e-3, f"story {i} of the batch vs alone ({hw}x{hw})")
 
 
 # ---- the sampling loop at the REAL width against reference-UNet-driven trajectories (RCDMs_pipeline.py:455-503) ------
 # golden: oracle/make_golden.py --only loop32|loop64 — the reference UNet3DConditionModel (1276.9 M parameters,
 # procedural weights, seed-42 story) inside the oracle's CFG + DDIM loop, latents stored after selected steps.
-# Random-init weights make eps non-noise-like, so |x| grows ~20x over the trajectory and the recurrence amplifies
-# differences; the tolerances below are <= 2x the drift measured on MI355X.
-LOOP_TOL = {32: dict(step=4e-3, end=2.5e-2), 64: dict(step=4e-3, end=4e-2)}
+# Measured on MI355X (32x32, 20 steps): drift 5.1e-4 after step 1, 8.2e-4 after step 20 (it saturates: with random-init
+# weights |x| grows ~20x, so late steps add little RELATIVE error); one step from a reference x_k: 3.7e-4 (k=1) falling
+# to 2e-6 (k=19).  Tolerances are <= 2.2x those numbers.
+LOOP_TOL = {32: dict(step=1e-3, end=1.8e-3), 64: dict(step=1.2e-3, end=2.5e-3)}
 
 
 def _full_loop(full_unet, hw, steps):
@@ -217,7 +219,7 @@ def test_denoise_loop_vs_oracle(hiplib, guidance):
     assert seen == [(0, 751), (1, 501), (2, 251), (3, 1)]
     with torch.no_grad():
         ref = O.denoise_loop(sd, cfg, s["latents"], s["mask"], s["masked_latents"], s["ctx"], 4, guidance)
-    check(out, ref, 4e-3, 1e-2, f"4-step loop gs={guidance}")
+    check(out, ref, 3.3e-3, 3e-3, f"4-step loop gs={guidance}")
     # replaying the same loop object is bit-reproducible, and eager == graph
     loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
     out2 = loop.run().clone()
@@ -244,4 +246,4 @@ def test_story_batch_equals_single_stories(hiplib):
         loop1 = DenoiseLoop(m, 1, 5, 16, 16, 13, 2.0, mk(), 3)
         loop1.load(s2["latents"][i:i + 1], mask, ml, ctx)
         one = loop1.run().clone().cpu()
-        check(both[i:i + 1], one, 2e-3, 1e-2, f"story {i} of a batch of 2 vs alone")
+        check(both[i:i + 1], one, 3.5e-3, 5e-3, f"story {i} of a batch of 2 vs alone")
