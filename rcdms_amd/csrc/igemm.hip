@@ -27,32 +27,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
+#include "igemm_args.h"
 
 namespace {
-
-constexpr int BK = 64;
-
-struct IgemmArgs {
-  const f16* A;
-  const f16* W;
-  const float* bias;
-  const float* rowvec;
-  const f16* res;
-  f16* out;
-  float* partial;
-  int M, N, Cin, Ktot;
-  int Hi, Wi, Ho, Wo, stride, up;
-  int pad;  // rows / columns of zero padding before the image: 1, or 0 for the pad-after-only form
-  int lda, ldc, ldr, ldt, rows_per_sample;
-  int epi;
-  float out_scale;
-  int tilesM, tilesN, kc, nk, splits, nk_per_split;
-  long long* trace;  // debug: per-block s_memtime stamps (rcdm_debug_set_igemm_trace), normally null
-};
-
-// GEGLU packing (rcdm_pack_geglu_rows): packed rows/columns come in groups of 64 = 32 "hidden" + their 32 "gate";
-// packed column n of a hidden value <-> output column (n>>6)*32 + (n&31); its gate sits at n + 32.
-__device__ __forceinline__ int geglu_out_col(int n) { return (n >> 6) * 32 + (n & 31); }
 
 // v: 8 accumulated values of row m at packed columns n..n+7 (GEGLU: g = the matching gate columns n+32..).
 // n is a multiple of 8, so every per-column vector (bias, row vector) is fetched as two aligned float4.
@@ -653,10 +630,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
 }
 
 // variant: 1 = 128x128 (2 blocks/CU), 2 = 256x256 (1), 3 = 64x64 two-slot ring (4), 4 = 64x64 four-slot ring (2),
-// 5 = 128x64 (3)   (-1 = heuristic)
+// 5 = 128x64 (3); 6 / 7 / 8 = the ping-pong kernel of igemm8.hip at 160x320 / 160x256 / 256x256   (-1 = heuristic)
 int g_force_variant = -1;
 struct TileCfg { int bm, bn, blocks_per_cu; };
-const TileCfg kTiles[6] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}, {64, 64, 4}, {64, 64, 2}, {128, 64, 3}};
+constexpr int kFirstPP = 6;
+const TileCfg kTiles[9] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}, {64, 64, 4}, {64, 64, 2}, {128, 64, 3},
+                           {160, 320, 1}, {160, 256, 1}, {256, 256, 1}};
+int g_pp_mode = -1;  // RCDM_PP=0: never pick the ping-pong kernel (A/B switch)
 int g_num_cus = 0;
 long long* g_trace = nullptr;
 
@@ -672,6 +652,51 @@ int num_cus() {
   return g_num_cus;
 }
 
+// Split-K for the ping-pong kernel: its tiles are big, so shapes with fewer tiles than CUs (M = 10240 / 2560 rows with
+// N = 640 / 1280) are cut along K until one round of the chip is full; a slice keeps >= 16 k-steps.
+int pp_splits(int tiles, int nk) {
+  int s = num_cus() / (tiles > 0 ? tiles : 1);
+  if (s > nk / 16) s = nk / 16;
+  if (s > 8) s = 8;
+  return s < 1 ? 1 : s;
+}
+
+// The ping-pong kernel (igemm8.hip).  Measured against the 128x128 / 256x256 one-barrier kernels (tools/kbench.py,
+// profiles/r2_pp_kbench.txt): it wins where its big tile comes out as whole rounds of the chip AND the k-loop is long
+// enough to amortise a prologue / epilogue that nothing overlaps (one block per CU): the conv3x3 of the 64x64 level
+// (160x320: exactly 256 tiles, 1.37-1.42x), the other convs with >= 2560 rows (1.04-1.07x), and the M = 40960 GEMMs
+// with N <= 960 (qkv 1.13x, feed-forward out 1.12x).  The K = 640 / 1280 GEMMs of the 32x32 / 16x16 levels stay on the
+// two-blocks-per-CU kernel, whose second block hides the epilogue.  Returns the shape index or -1.
+int pick_pp(const IgemmArgs& a) {
+  const int taps = a.Ktot / a.Cin;
+  const int nk = (a.Cin + BK - 1) / BK * taps;
+  if (a.M < 2048 || a.N < 256) return -1;
+  if (taps == 1) {
+    if (a.M < 20480 || a.N > 1024) return -1;
+    if (!(nk >= 16 || (a.N >= 640 && nk >= 5))) return -1;
+  } else if (nk < 40) {
+    return -1;
+  }
+  const int cus = num_cus();
+  int best = -1;
+  float best_score = 0.80f;
+  for (int sh = 0; sh < kNumPPShapes; ++sh) {
+    const int bm = kPPShapes[sh].bm, bn = kPPShapes[sh].bn;
+    const int tm = (a.M + bm - 1) / bm, tn = (a.N + bn - 1) / bn, tiles = tm * tn;
+    const int sp = tiles < cus ? pp_splits(tiles, nk) : 1;
+    const int work = tiles * sp, rounds = (work + cus - 1) / cus;
+    const float useful = (float)a.M * (float)a.N / ((float)tiles * bm * bn);
+    const float fill = (float)work / (float)(rounds * cus);
+    float score = useful * fill * (sp > 1 ? 0.90f : 1.0f);
+    if (sh == 2) score *= 1.03f;  // 256x256 moves fewer operand bytes per flop
+    if (score > best_score) {
+      best_score = score;
+      best = sh;
+    }
+  }
+  return best;
+}
+
 int pick_variant(const IgemmArgs& a) {
   if (g_force_variant < 0) {
     const char* e = getenv("RCDM_IGEMM");
@@ -681,6 +706,14 @@ int pick_variant(const IgemmArgs& a) {
     if (e && !strcmp(e, "dma64")) g_force_variant = 3;
   }
   if (g_force_variant != 99) return g_force_variant == 0 ? 1 : g_force_variant;
+  if (g_pp_mode < 0) {
+    const char* e = getenv("RCDM_PP");
+    g_pp_mode = e ? atoi(e) : 1;
+  }
+  if (g_pp_mode) {
+    const int pp = pick_pp(a);
+    if (pp >= 0) return kFirstPP + pp;
+  }
   // measured (tools/kbench.py, MI355X).  128x128 with two blocks per CU is the default.  Shapes that leave most CUs
   // without a 128x128 tile (8x8 / 16x16 levels, context K/V projections) run as 64x64 or 128x64 tiles so that several
   // blocks per CU keep more DMA in flight; N = 320 / 960 (half a 128-wide tile wasted) with a short K take 128x64;
@@ -727,7 +760,13 @@ int fill_common(IgemmArgs& a, int requested_split, int* variant_out = nullptr) {
   a.kc = (a.Cin + BK - 1) / BK;
   const int taps = a.Ktot / a.Cin;
   a.nk = taps * a.kc;
-  int s = plan_splits(a.tilesM * a.tilesN, num_cus() * tc.blocks_per_cu, a.nk, requested_split);
+  int s;
+  if (variant >= kFirstPP && requested_split <= 0) {
+    const int tiles = a.tilesM * a.tilesN;
+    s = tiles < num_cus() ? pp_splits(tiles, a.nk) : 1;
+  } else {
+    s = plan_splits(a.tilesM * a.tilesN, num_cus() * tc.blocks_per_cu, a.nk, requested_split);
+  }
   if (s > a.nk) s = a.nk;
   a.nk_per_split = (a.nk + s - 1) / s;
   a.splits = (a.nk + a.nk_per_split - 1) / a.nk_per_split;
@@ -783,6 +822,26 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
     a.partial = nullptr;
   }
   a.trace = g_trace;
+  a.dbg = 0;
+  if (variant >= kFirstPP) {
+    static int rotate = -1;
+    if (rotate < 0) {
+      const char* e = getenv("RCDM_PP_ROTATE");
+      rotate = e ? atoi(e) : 0;   // measured: no gain (the weight stream is not hot-spotting L2 channels)
+    }
+    a.dbg = rotate ? 8 : 0;
+    int rc = rcdm_igemm_pp_launch(a, TAPS, variant - kFirstPP, stream);
+    if (rc) return rc;
+    if (a.splits > 1) {
+      const bool geglu = (a.epi & RCDM_EPI_GEGLU) != 0;
+      const size_t total = (size_t)a.M * ((geglu ? a.N / 2 : a.N) / 8);
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+      rc = rcdm_check_launch();
+    }
+    return rc;
+  }
   const int ntiles = a.tilesM * a.tilesN;
   int gx = num_cus() * kTiles[variant].blocks_per_cu;
   if (a.splits > 1) gx = (gx + a.splits - 1) / a.splits;
@@ -856,8 +915,13 @@ int from_conv(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
 extern "C" {
 
 int rcdm_set_igemm_variant(int32_t v) {
-  if (v < -1 || v > 5) return RCDM_EINVAL;
+  if (v < -1 || v > 8) return RCDM_EINVAL;
   g_force_variant = v < 0 ? 99 : v;
+  return RCDM_OK;
+}
+
+int rcdm_set_igemm_pingpong(int32_t on) {
+  g_pp_mode = on ? 1 : 0;
   return RCDM_OK;
 }
 

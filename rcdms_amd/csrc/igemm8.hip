@@ -1,0 +1,511 @@
+// igemm8.hip — 8-wave PING-PONG implicit GEMM for gfx950 (Linear / 1x1 conv and conv3x3 over channels-last f16
+// rows, fp32 accumulate): the deep-K, many-row shapes of the UNet (GEGLU / qkv / feed-forward GEMMs and the convs of the
+// 64x64 .. 16x16 levels).  Same operands, epilogues and C-ABI entry points as igemm.hip (rcdm_gemm / rcdm_conv3x3 pick
+// the kernel by shape); replaces the same reference calls (InflatedConv3d.forward src/models/resnet.py:10-18, the
+// nn.Linear calls of attention.py:121,140-141,164, diffusers FeedForward).
+//
+// Why a second loop: igemm_dma_kernel keeps ONE barrier per 64-deep k-step and lets every wave do
+// [DMA issue -> ds_read -> MFMA] in the same order, so both waves of a SIMD stall on the vector-memory queue at the
+// same time (measured: MFMA pipe 33-35 % busy at the 64x64 level, 62 % inside the k-loop).  Here the block's 8 waves
+// form two groups of 4 (one wave of each group per SIMD) that run HALF A K-STEP OUT OF PHASE:
+//     tick            4g        4g+1      4g+2      4g+3
+//     group 0 (rows 0..BM/2)    L(g,0)    C(g,0)    L(g,1)    C(g,1)
+//     group 1 (rows BM/2..BM)   C(g-1,1)  L(g,0)    C(g,0)    L(g,1)
+// L = load phase: ds_read the fragments of one 32-deep half k-step into registers + issue this wave's LDS-DMA pieces;
+// C = compute phase: FMW x FNW v_mfma_f32_16x16x32_f16 back to back at raised priority.  One s_barrier per tick keeps
+// the two groups in lock-step, so the matrix pipe of every SIMD always has one wave in C while its partner is in L.
+// Tiles are multiples of 16 (16x16x32 fragments), chosen so that M = 40960 / 10240 / 2560 rows split into an EXACT
+// number of rounds over the 256 CUs: 160x320 (256 row tiles at the 64x64 level), 160x256, 256x256.
+//
+// LDS (all 160 KB for the 160x320 and 256x256 tiles): a ring of 2 pixel tiles [BM rows][128 B] and a ring of 3 weight
+// tiles [BN rows][128 B], written by buffer_load ... lds (lane-linear 1-KiB pieces, XOR swizzle on the source side exactly
+// as igemm.hip).  Measured with the compute ablated (RCDM_PP_ABLATE): the k-loop without DMA runs 0.93 us per 160x320x64
+// k-step, the DMA stream alone 1.15-1.2 us — latency, not bandwidth: a part is ~1.1 us from issue to landed under load,
+// and with two weight tiles a weight part could only be issued 2-3 ticks (0.5-0.7 us) before its first read (a deeper
+// PIXEL ring changed nothing).  Hence three weight tiles: every part now has >= 4 ticks in flight.
+// A tile is released in parts as the out-of-phase groups finish with it and refilled one part per L phase:
+//     group 0, L(g,0) tick 4g  : pixel rows of group 1 (free since tick 4g-1)               -> k-step g+1
+//     group 1, L(g,0) tick 4g+1: upper half of the weight rows (tile of k-step g-1)         -> k-step g+2
+//     group 0, L(g,1) tick 4g+2: lower half of the weight rows                              -> k-step g+2
+//     group 1, L(g,1) tick 4g+3: pixel rows of group 0 (last read one tick earlier)         -> k-step g+2
+// Waits are counted vmcnt ("all but the newest pixel part + weight part of this wave"), placed before the barriers that
+// close ticks 4g (group 0), 4g+3 (both).
+// Pieces that do not divide over 4 waves (BM/2 = 80 rows = 10 pieces: waves 0,1 issue 3, waves 2,3 issue 2) make the
+// vmcnt immediates wave-dependent: picked by a wave-uniform branch.
+#include "common.h"
+#include "igemm_args.h"
+
+const PPShape kPPShapes[kNumPPShapes] = {{160, 320}, {160, 256}, {256, 256}};
+
+namespace {
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void tick_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n in [0, 12]
+__device__ __forceinline__ void wait_vm_n(int n) {
+  switch (n) {
+    case 0: wait_vm<0>(); break;
+    case 1: wait_vm<1>(); break;
+    case 2: wait_vm<2>(); break;
+    case 3: wait_vm<3>(); break;
+    case 4: wait_vm<4>(); break;
+    case 5: wait_vm<5>(); break;
+    case 6: wait_vm<6>(); break;
+    case 7: wait_vm<7>(); break;
+    case 8: wait_vm<8>(); break;
+    case 9: wait_vm<9>(); break;
+    case 10: wait_vm<10>(); break;
+    case 11: wait_vm<11>(); break;
+    default: wait_vm<12>(); break;
+  }
+}
+
+template <int TAPS, int FMW, int FNW, bool SLAB>
+__global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
+  constexpr int BM = 2 * FMW * 16, BN = 4 * FNW * 16;
+  constexpr int HM = BM / 2, HN = BN / 2;         // rows of one pixel half / one weight half
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
+  constexpr int W_RING = 2 * A_BYTES;             // 3 weight tiles behind the 2 pixel tiles
+  constexpr int PP = HM / 8;                      // 1-KiB pieces per pixel half
+  constexpr int NPP = (PP + 3) / 4;               // ... per wave (the last one may be missing: see npp)
+  constexpr int NPW = HN / 32;                    // weight-half pieces per wave
+  static_assert(2 * A_BYTES + 3 * W_BYTES <= 160 * 1024, "ring exceeds the LDS");
+  static_assert(HN % 32 == 0 && HM % 8 == 0, "tile halves must be whole pieces");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+
+  const int ks_begin = blockIdx.y * p.nk_per_split;
+  const int nkl = min(p.nk, ks_begin + p.nk_per_split) - ks_begin;
+  if (nkl <= 0) return;
+
+  // XCD-aware, L2-blocked tile order (see igemm.hip): block b runs on XCD b % 8 and each XCD gets a contiguous run of
+  // the sequence "super-rows of 8 row panels, column by column".
+  int cm0, cn0;
+  {
+    const int ntiles = p.tilesM * p.tilesN, lin = blockIdx.x;
+    const int xcd = lin & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int tl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    constexpr int GM = 8;
+    const int per_group = GM * p.tilesN;
+    const int sg = tl / per_group, rem = tl - sg * per_group;
+    const int gm = min(GM, p.tilesM - sg * GM);
+    const int tn = rem / gm, tm = sg * GM + (rem - tn * gm);
+    cm0 = tm * BM;
+    cn0 = tn * BN;
+  }
+
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7FFFFFFF, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const int Hv = p.Hi << p.up, Wv = p.Wi << p.up;
+
+  // ---- loader state: every group fills the OTHER group's pixel rows; group 0 the lower weight rows, group 1 the upper
+  const int myhalf = grp ^ 1, mywhalf = grp;
+  const int lrow = lane >> 3, lch = lane & 7;
+  unsigned a_off[NPP], w_off[NPW];
+  int a_img[NPP], a_iy[NPP], a_ix[NPP], a_c[NPP], a_lds[NPP], w_c[NPW], w_lds[NPW];
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) {
+    const int q = wn + 4 * i;
+    const bool live = q < PP;
+    const int row = myhalf * HM + q * 8 + lrow;  // row of the pixel tile
+    const int m = cm0 + row;
+    a_lds[i] = live ? (myhalf * HM + q * 8) * 128 : -1;
+    a_c[i] = (lch ^ ((row >> 1) & 7)) * 8;
+    a_off[i] = OOB;
+    a_img[i] = a_ix[i] = 0;
+    a_iy[i] = -(1 << 20);
+    if (TAPS == 1) {
+      if (live && m < p.M) a_off[i] = (unsigned)m * (unsigned)p.lda * 2u;
+    } else if (live && m < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int img = m / hw, rem = m - img * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_img[i] = img * p.Hi * p.Wi;  // first pixel row of the image
+      a_iy[i] = oy * p.stride - p.pad;
+      a_ix[i] = ox * p.stride - p.pad;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int q = wn + 4 * i;
+    const int row = mywhalf * HN + q * 8 + lrow;  // row of the weight tile
+    const int n = cn0 + row;
+    w_lds[i] = W_RING + (mywhalf * HN + q * 8) * 128;
+    w_c[i] = (lch ^ ((row >> 1) & 7)) * 8;
+    w_off[i] = n < p.N ? (unsigned)n * (unsigned)p.Ktot * 2u : OOB;
+  }
+
+  // Every tile of an XCD that shares a weight panel would otherwise stream the SAME weight lines at the same moment
+  // (32 CUs on one L2 channel at a time).  Each block therefore starts its k-loop at a different k-step (conv: at a
+  // different 64-channel slab, so the nine taps of a slab stay adjacent) and wraps around.
+  int rot = 0;
+  if (p.dbg & 8) {
+    const int idx = blockIdx.x >> 3;  // position inside the XCD's run of tiles
+    rot = TAPS == 1 ? idx % nkl : (9 * idx) % nkl;
+  }
+  auto kpos = [&](int ks, int& c0, int& tap) __attribute__((always_inline)) {
+    ks += rot;
+    if (ks >= nkl) ks -= nkl;
+    ks += ks_begin;
+    tap = 0;
+    int kci = ks;
+    if (TAPS != 1) {  // channel chunk outer, tap inner (the nine windows of one 64-channel slab re-hit L2)
+      kci = ks / 9;
+      tap = ks - kci * 9;
+    }
+    c0 = kci * BK;
+  };
+  auto issue_px = [&](int ks) __attribute__((always_inline)) {
+    const int slot = ks & 1;
+    int c0, tap;
+    kpos(ks, c0, tap);
+    const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const int c = c0 + a_c[i];
+      unsigned vo;
+      if (TAPS == 1) {
+        vo = (c < p.Cin && a_off[i] != OOB) ? a_off[i] + (unsigned)c * 2u : OOB;
+      } else {
+        const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+        const bool ok = (c < p.Cin) && ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+        const int sy = iy >> p.up, sx = ix >> p.up;
+        // computed unconditionally (a select, not a branch: no address is dereferenced here)
+        const unsigned off = ((unsigned)(a_img[i] + sy * p.Wi + sx) * (unsigned)p.lda + (unsigned)c) * 2u;
+        vo = ok ? off : OOB;
+      }
+      if (a_lds[i] >= 0)  // wave-uniform: the waves whose last piece does not exist issue one DMA fewer
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrcA, (__attribute__((address_space(3))) void*)(smem + slot * A_BYTES + a_lds[i]), 16, vo, 0, 0, 0);
+    }
+  };
+  auto issue_w = [&](int ks) __attribute__((always_inline)) {
+    const int slot = ks % 3;
+    int c0, tap;
+    kpos(ks, c0, tap);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int c = c0 + w_c[i];
+      const unsigned vo = (c < p.Cin && w_off[i] != OOB)
+                              ? w_off[i] + ((unsigned)tap * (unsigned)p.Cin + (unsigned)c) * 2u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrcW, (__attribute__((address_space(3))) void*)(smem + slot * W_BYTES + w_lds[i]), 16, vo, 0, 0, 0);
+    }
+  };
+
+  // ---- compute mapping: 16x16x32 fragments; weights are the A operand, pixels the B operand -> D[channel][pixel]
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int sw = (lane >> 1) & 7;  // (row >> 1) & 7 of this lane's fragment rows (fragment bases are multiples of 16)
+  const int koff0 = ((kg ^ sw) << 4), koff1 = (((4 + kg) ^ sw) << 4);
+  const int rowA = (grp * HM + l15) * 128, rowB = W_RING + (wn * (BN / 4) + l15) * 128;
+
+  f32x4 acc[FNW][FMW];
+#pragma unroll
+  for (int i = 0; i < FNW; ++i)
+#pragma unroll
+    for (int j = 0; j < FMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f16x8 wf[FNW], xf[FMW];
+
+#ifdef RCDM_PP_ABLATE  // debug builds only (rcdms_amd.build.build_variant): 1 no DMA after the prologue, 2 no MFMA, 4 no ds_read
+  constexpr bool no_dma = (RCDM_PP_ABLATE & 1) != 0, no_mfma = (RCDM_PP_ABLATE & 2) != 0, no_read = (RCDM_PP_ABLATE & 4) != 0;
+#else
+  constexpr bool no_dma = false, no_mfma = false, no_read = false;
+#endif
+  auto load_frags = [&](int aslot, int wslot, int koff) __attribute__((always_inline)) {
+    if (no_read) return;
+    const char* sa = smem + aslot * A_BYTES + rowA + koff;
+    const char* sb = smem + wslot * W_BYTES + rowB + koff;
+#pragma unroll
+    for (int i = 0; i < FNW; ++i) wf[i] = *(const f16x8*)(sb + i * 2048);
+#pragma unroll
+    for (int j = 0; j < FMW; ++j) xf[j] = *(const f16x8*)(sa + j * 2048);
+  };
+  auto compute = [&]() __attribute__((always_inline)) {
+    if (no_mfma) return;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < FNW; ++i)
+#pragma unroll
+      for (int j = 0; j < FMW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // DMAs this wave has in flight when "its newest pixel part + its newest weight part" are outstanding
+  const int npp = (wn + 4 * (NPP - 1) < PP) ? NPP : NPP - 1;
+  const int keep = npp + NPW;
+
+  // ---- prologue: all of k-step 0 and what the steady state would have issued before tick 0: both weight halves of
+  // k-step 1 and (group 1) the group-0 pixel rows of k-step 1.  Issue order = the order the loop's counted waits assume.
+  if (grp == 1) {
+    issue_px(0);
+    issue_w(0);
+    if (nkl > 1) {
+      issue_w(1);
+      issue_px(1);
+      wait_vm_n(keep);
+    } else {
+      wait_vm<0>();
+    }
+  } else {
+    issue_px(0);
+    issue_w(0);
+    if (nkl > 1) {
+      issue_w(1);
+      wait_vm<NPW>();
+    } else {
+      wait_vm<0>();
+    }
+  }
+  tick_barrier();
+
+  if (grp == 0) {
+    int wslot = 0;  // g % 3
+    for (int g = 0; g < nkl; ++g) {
+      const int aslot = g & 1;
+      // tick 4g: L(g,0).  Group 1 reads its pixel rows of THIS k-step one tick from now (issued in tick 4g-4): all but
+      // the newest pixel part and the weight part before it must have landed.
+      load_frags(aslot, wslot, koff0);
+      if (g + 1 < nkl && !no_dma) {
+        issue_px(g + 1);
+        wait_lgkm0();
+        wait_vm_n(keep);
+      } else {
+        wait_lgkm0();
+        wait_vm<0>();
+      }
+      tick_barrier();
+      // tick 4g+1: C(g,0)
+      compute();
+      tick_barrier();
+      // tick 4g+2: L(g,1): the weight tile of k-step g-1 is free since tick 4g-1 -> lower half of k-step g+2
+      load_frags(aslot, wslot, koff1);
+      const bool more_w = g + 2 < nkl && !no_dma;
+      if (more_w) issue_w(g + 2);
+      wait_lgkm0();
+      tick_barrier();
+      // tick 4g+3: C(g,1); the lower weight rows of k-step g+1 (issued in tick 4g-2) must have landed
+      compute();
+      if (more_w) wait_vm_n(keep); else wait_vm<0>();
+      tick_barrier();
+      wslot = wslot == 2 ? 0 : wslot + 1;
+    }
+    tick_barrier();  // tick 4 nkl: group 1's last compute phase
+  } else {
+    tick_barrier();  // tick 0: group 0's first load phase
+    int wslot = 0;
+    for (int g = 0; g < nkl; ++g) {
+      const int aslot = g & 1;
+      const bool more = g + 2 < nkl && !no_dma;
+      // tick 4g+1: L(g,0): upper half of the weight rows of k-step g+2
+      load_frags(aslot, wslot, koff0);
+      if (more) issue_w(g + 2);
+      wait_lgkm0();
+      tick_barrier();
+      // tick 4g+2: C(g,0)
+      compute();
+      tick_barrier();
+      // tick 4g+3: L(g,1); group 0 finished with its pixel rows of k-step g one tick ago -> refill them for g+2;
+      // its pixel rows and the upper weight rows of k-step g+1 must have landed
+      load_frags(aslot, wslot, koff1);
+      if (more) {
+        issue_px(g + 2);
+        wait_lgkm0();
+        wait_vm_n(keep);
+      } else {
+        wait_lgkm0();
+        wait_vm<0>();
+      }
+      tick_barrier();
+      // tick 4g+4: C(g,1)
+      compute();
+      tick_barrier();
+      wslot = wslot == 2 ? 0 : wslot + 1;
+    }
+  }
+  // every wave is past the last tick: no LDS read and no DMA is outstanding anywhere in the block
+
+  if constexpr (SLAB) {
+    // ---- split-K: the fp32 tile goes to this split's slab (16 B per lane, 64-B runs per pixel row); bias / row
+    // vector / residual / GEGLU belong to splitk_reduce_kernel
+    float* dst = p.partial + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < FMW; ++j) {
+      const int m = cm0 + grp * HM + j * 16 + l15;
+#pragma unroll
+      for (int i = 0; i < FNW; ++i) {
+        const int n = cn0 + wn * (BN / 4) + i * 16 + 4 * kg;
+        if (m < p.M && n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
+      }
+    }
+  } else {
+    // ---- fused epilogue: accumulators -> f16 tile in LDS ([BM][BN] halfs, rows padded by 16 B: the 16 lanes of a
+    // ds_write_b64 group fall in 16 different bank pairs) -> coalesced 16-byte-per-lane pass with bias / per-sample row
+    // vector / GELU / GEGLU / residual / scale in fp32
+    constexpr int RS = 2 * BN + 16;
+#pragma unroll
+    for (int j = 0; j < FMW; ++j) {
+      const int row = grp * HM + j * 16 + l15;
+#pragma unroll
+      for (int i = 0; i < FNW; ++i) {
+        const int col = wn * (BN / 4) + i * 16 + 4 * kg;
+        union { f16 h[4]; uint2 u; } pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.h[e] = (f16)acc[i][j][e];
+        *(uint2*)(smem + row * RS + col * 2) = pk.u;
+      }
+    }
+    wait_lgkm0();
+    tick_barrier();
+    const float sc = p.out_scale;
+    constexpr int U = 4;
+    if (p.epi & RCDM_EPI_GEGLU) {
+      constexpr int CPR = BN / 16;  // output chunks (8 hidden columns) per row
+      constexpr int ITEMS = BM * CPR;
+      const int oc0 = geglu_out_col(cn0);
+      for (int base = 0; base < ITEMS; base += 512 * U) {
+        Pack16 hh[U], gg[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = min(base + u * 512 + t, ITEMS - 1);
+          const int row = idx / CPR, c = idx - row * CPR;
+          const int hc = (c >> 2) * 8 + (c & 3);
+          hh[u].u = *(const uint4*)(smem + row * RS + hc * 16);
+          gg[u].u = *(const uint4*)(smem + row * RS + (hc + 4) * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * 512 + t;
+          const int row = idx / CPR, c = idx - row * CPR;
+          const int hc = (c >> 2) * 8 + (c & 3);
+          const int m = cm0 + row, pn = cn0 + hc * 8;
+          if (idx < ITEMS && m < p.M && pn < p.N) {
+            float bh[8], bg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bh[e] = bg[e] = 0.f;
+            if (p.epi & RCDM_EPI_BIAS) {
+              const f32x4 a0 = *(const f32x4*)(p.bias + pn), a1 = *(const f32x4*)(p.bias + pn + 4);
+              const f32x4 b0 = *(const f32x4*)(p.bias + pn + 32), b1 = *(const f32x4*)(p.bias + pn + 36);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                bh[e] = a0[e]; bh[4 + e] = a1[e];
+                bg[e] = b0[e]; bg[4 + e] = b1[e];
+              }
+            }
+            Pack16 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              o.e[e] = (f16)(((float)hh[u].e[e] + bh[e]) * gelu_f((float)gg[u].e[e] + bg[e]) * sc);
+            *(uint4*)(p.out + (size_t)m * p.ldc + oc0 + c * 8) = o.u;
+          }
+        }
+      }
+    } else {
+      constexpr int CPR = BN / 8;
+      constexpr int ITEMS = BM * CPR;
+      const bool has_res = (p.epi & RCDM_EPI_RESIDUAL) != 0;
+      for (int base = 0; base < ITEMS; base += 512 * U) {
+        Pack16 hh[U], rr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = min(base + u * 512 + t, ITEMS - 1);
+          const int row = idx / CPR, c8 = idx - row * CPR;
+          const int m = cm0 + row, n = cn0 + c8 * 8;
+          hh[u].u = *(const uint4*)(smem + row * RS + c8 * 16);
+          rr[u].u = make_uint4(0, 0, 0, 0);
+          if (has_res && base + u * 512 + t < ITEMS && m < p.M && n < p.N)
+            rr[u].u = *(const uint4*)(p.res + (size_t)m * p.ldr + n);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * 512 + t;
+          const int row = idx / CPR, c8 = idx - row * CPR;
+          const int m = cm0 + row, n = cn0 + c8 * 8;
+          if (idx < ITEMS && m < p.M && n < p.N) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)hh[u].e[e];
+            if (p.epi & RCDM_EPI_BIAS) {
+              const f32x4 a0 = *(const f32x4*)(p.bias + n), a1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[e] += a0[e];
+                v[4 + e] += a1[e];
+              }
+            }
+            if (p.epi & RCDM_EPI_ROWVEC) {
+              const float* rv = p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + n;
+              const f32x4 a0 = *(const f32x4*)rv, a1 = *(const f32x4*)(rv + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[e] += a0[e];
+                v[4 + e] += a1[e];
+              }
+            }
+            if (p.epi & RCDM_EPI_GELU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            }
+            Pack16 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + (float)rr[u].e[e]) * sc);
+            *(uint4*)(p.out + (size_t)m * p.ldc + n) = o.u;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int FMW, int FNW>
+constexpr int pp_lds_bytes() {
+  constexpr int BM = 2 * FMW * 16, BN = 4 * FNW * 16;
+  constexpr int ring = (2 * BM + 3 * BN) * 128, stage = BM * (2 * BN + 16);
+  return ring > stage ? ring : stage;
+}
+
+template <int TAPS, int FMW, int FNW>
+int launch_pp(const IgemmArgs& a, hipStream_t stream) {
+  constexpr int LDS = pp_lds_bytes<FMW, FNW>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<TAPS, FMW, FNW, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<TAPS, FMW, FNW, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  dim3 grid(a.tilesM * a.tilesN, a.splits);
+  if (a.splits > 1)
+    hipLaunchKernelGGL((igemm_pp_kernel<TAPS, FMW, FNW, true>), grid, dim3(512), LDS, stream, a);
+  else
+    hipLaunchKernelGGL((igemm_pp_kernel<TAPS, FMW, FNW, false>), grid, dim3(512), LDS, stream, a);
+  return rcdm_check_launch();
+}
+
+template <int TAPS>
+int launch_shape(const IgemmArgs& a, int shape, hipStream_t stream) {
+  switch (shape) {
+    case 0: return launch_pp<TAPS, 5, 5>(a, stream);
+    case 1: return launch_pp<TAPS, 5, 4>(a, stream);
+    case 2: return launch_pp<TAPS, 8, 4>(a, stream);
+    default: return RCDM_EINVAL;
+  }
+}
+
+}  // namespace
+
+int rcdm_igemm_pp_launch(const IgemmArgs& a, int taps, int shape, hipStream_t stream) {
+  if (taps == 1) return launch_shape<1>(a, shape, stream);
+  if (taps == 9) return launch_shape<9>(a, shape, stream);
+  return RCDM_EINVAL;
+}

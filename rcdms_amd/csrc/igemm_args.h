@@ -1,0 +1,37 @@
+// igemm_args.h — launch arguments shared by the two implicit-GEMM kernel families of librcdm_hip.so:
+// igemm.hip (igemm_dma_kernel: 4-wave 128x128 / 64x64 / 128x64 tiles and the 8-wave 256x256 one-barrier loop) and
+// igemm8.hip (igemm_pp_kernel: 8-wave ping-pong loop, 160x320 / 160x256 / 256x256 tiles).
+#pragma once
+#include "common.h"
+
+constexpr int BK = 64;
+
+struct IgemmArgs {
+  const f16* A;
+  const f16* W;
+  const float* bias;
+  const float* rowvec;
+  const f16* res;
+  f16* out;
+  float* partial;
+  int M, N, Cin, Ktot;
+  int Hi, Wi, Ho, Wo, stride, up;
+  int pad;  // rows / columns of zero padding before the image: 1, or 0 for the pad-after-only form
+  int lda, ldc, ldr, ldt, rows_per_sample;
+  int epi;
+  float out_scale;
+  int tilesM, tilesN, kc, nk, splits, nk_per_split;
+  long long* trace;  // debug: per-block s_memtime stamps (rcdm_debug_set_igemm_trace), normally null
+  int dbg;           // ping-pong loop switches: 8 = rotate the k order per block (RCDM_PP_ROTATE, default on)
+};
+
+// GEGLU packing (rcdm_pack_geglu_rows): packed rows/columns come in groups of 64 = 32 "hidden" + their 32 "gate";
+// packed column n of a hidden value <-> output column (n>>6)*32 + (n&31); its gate sits at n + 32.
+__host__ __device__ __forceinline__ int geglu_out_col(int n) { return (n >> 6) * 32 + (n & 31); }
+
+// igemm8.hip: ping-pong tile shapes (index into kPPShapes), launched by igemm.hip's dispatcher
+struct PPShape { int bm, bn; };
+constexpr int kNumPPShapes = 3;
+extern const PPShape kPPShapes[kNumPPShapes];
+// taps = 1 | 9; a.tilesM/tilesN/splits/nk_per_split/partial already planned for the shape.  Returns an RCDM_* code.
+int rcdm_igemm_pp_launch(const IgemmArgs& a, int taps, int shape, hipStream_t stream);

@@ -64,6 +64,7 @@ SYMBOLS = {
     "rcdm_last_hip_error_string": (C.c_char_p, []),
     "rcdm_gemm_workspace_bytes": (_SZ, [C.POINTER(GemmDesc)]),
     "rcdm_set_igemm_variant": (C.c_int, [_I]),
+    "rcdm_set_igemm_pingpong": (C.c_int, [_I]),
     "rcdm_debug_set_igemm_trace": (C.c_int, [_P]),
     "rcdm_debug_mfma_peak": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P]),
     "rcdm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -144,6 +145,10 @@ def ptr(t):
 
 def set_igemm_variant(v):
     _check(load().rcdm_set_igemm_variant(v), "rcdm_set_igemm_variant")
+
+
+def set_igemm_pingpong(on):
+    _check(load().rcdm_set_igemm_pingpong(int(bool(on))), "rcdm_set_igemm_pingpong")
 
 
 def gemm_workspace_bytes(desc):

@@ -61,7 +61,7 @@ def ws(nbytes):
     (260, 64, 64, 1 | 2 | 4, 1),     # row vector with fewer rows per sample (100) than a 128-row tile: in-place reads
     (400, 320, 128, 1 | 2 | 4, 1),
 ])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm(hiplib, M, N, K, epi, split, variant):
     from rcdms_amd import hip
     hip.set_igemm_variant(variant)
@@ -110,7 +110,74 @@ def test_gemm_transpose_detecting(hiplib):
     close(out, W.t(), rel=1e-3, abs_frac=1e-3)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [6, 7, 8])
+@pytest.mark.parametrize("M,N,K,epi,split", [
+    (700, 648, 1000, 1 | 4, 1),      # several tiles both ways, ragged M / N, K tail (15 k-steps + 40), bias + residual
+    (1280, 640, 704, 1, 0),          # 11 k-steps (odd), heuristic split
+    (512, 512, 64, 0, 1),            # a single k-step: prologue -> epilogue with no steady-state tick
+    (512, 512, 128, 1 | 16, 1),      # two k-steps, GELU epilogue
+    (2560, 1280, 2560, 1 | 4, 0),    # M = 2560 level: fewer tiles than CUs -> split-K slabs + reduce
+    (330, 330 // 8 * 8, 1920, 1 | 2, 1),
+])
+def test_gemm_pingpong(hiplib, M, N, K, epi, split, variant):
+    """The 8-wave ping-pong kernel (igemm8.hip) at shapes that exercise its slot-release schedule: odd / even / tiny
+    k-step counts, tiles ragged in M and N, the fused and the split-K (slab) epilogues."""
+    from rcdms_amd import hip
+    hip.set_igemm_variant(variant)
+    g = torch.Generator().manual_seed(4321 + M + N + K)
+    A = h16(torch.randn(M, K, generator=g))
+    W = h16(torch.randn(N, K, generator=g) * K ** -0.5)
+    bias = torch.randn(N, generator=g)
+    rps = 150
+    rowvec = torch.randn((M + rps - 1) // rps, N, generator=g)
+    res = h16(torch.randn(M, N, generator=g))
+    ref = A @ W.t()
+    if epi & 1:
+        ref = ref + bias
+    if epi & 2:
+        ref = ref + rowvec[torch.arange(M) // rps]
+    if epi & 16:
+        ref = F.gelu(ref)
+    if epi & 4:
+        ref = ref + res
+    Ad, Wd, Rd = A.half().to(DEV), W.half().to(DEV), res.half().to(DEV)
+    bd, rvd = bias.to(DEV), rowvec.to(DEV)
+    out = torch.full((M, N + 8), float("nan"), dtype=torch.float16, device=DEV)
+    d = hip.GemmDesc(M, N, K, K, N + 8, N, epi, rps, N, 1.0, split)
+    w = ws(hip.gemm_workspace_bytes(d))
+    for _ in range(2):   # twice: a stale-LDS or missed-wait race rarely shows on a cold first launch only
+        hip.gemm(d, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), rvd.data_ptr(), Rd.data_ptr(), out.data_ptr(),
+                 w.data_ptr(), w.numel())
+    torch.cuda.synchronize()
+    hip.set_igemm_variant(-1)
+    close(out[:, :N], ref)
+    assert torch.isnan(out[:, N:].float()).all(), "wrote outside the N columns"
+
+
+@pytest.mark.parametrize("variant", [6, 7, 8])
+def test_gemm_pingpong_bitwise_vs_128(hiplib, variant):
+    """Same k order inside a tile -> the ping-pong kernel and the 128x128 kernel agree BIT FOR BIT without split-K
+    (fp32 accumulation over k in the same 32-deep MFMA steps? no: 16x16x32 vs 32x32x16 group k differently, so only
+    near-equality is required) — and repeated launches of the ping-pong kernel are bit-identical (no race)."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 1600, 960, 1280
+    Ad = h16(torch.randn(M, K, generator=g)).half().to(DEV)
+    Wd = h16(torch.randn(N, K, generator=g) * K ** -0.5).half().to(DEV)
+    d = hip.GemmDesc(M, N, K, K, N, 0, 0, 1, 0, 1.0, 1)
+    outs = []
+    for v in (variant, variant, variant, 1):
+        hip.set_igemm_variant(v)
+        o = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        hip.gemm(d, Ad.data_ptr(), Wd.data_ptr(), 0, 0, 0, o.data_ptr(), 0, 0)
+        torch.cuda.synchronize()
+        outs.append(o)
+    hip.set_igemm_variant(-1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "ping-pong kernel is not deterministic"
+    close(outs[0], outs[3].float(), rel=2e-3, abs_frac=1e-3)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("split", [1, 2])
 def test_gemm_geglu(hiplib, split, variant):
     from rcdms_amd import hip
@@ -142,8 +209,9 @@ def test_gemm_geglu(hiplib, split, variant):
     (1, 5, 16, 16, 64, 64, 2, 0, 1),    # Downsample3D
     (1, 5, 8, 8, 128, 64, 1, 1, 1),     # Upsample3D folded into the conv
     (2, 1, 8, 8, 320, 320, 1, 0, 4),    # split-K
+    (2, 5, 16, 16, 128, 320, 1, 0, 0),  # 2560 pixels: several 160-row tiles, 18 k-steps, heuristic split
 ])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split, variant):
     from rcdms_amd import hip
     hip.set_igemm_variant(variant)

@@ -62,10 +62,13 @@ GEMMS = [  # (name, M, N, K, epi)
 ]
 CONVS = [  # (name, n_img, H, W, cin, cout)
     ("L0 320->320 @64", 10, 64, 64, 320, 320),
+    ("L0 640->320 @64", 10, 64, 64, 640, 320),
     ("L0 960->320 @64", 10, 64, 64, 960, 320),
     ("L1 640->640 @32", 10, 32, 32, 640, 640),
+    ("L1 1280->640 @32", 10, 32, 32, 1280, 640),
     ("L1 1920->640 @32", 10, 32, 32, 1920, 640),
     ("L2 1280->1280 @16", 10, 16, 16, 1280, 1280),
+    ("L2 2560->1280 @16", 10, 16, 16, 2560, 1280),
     ("L3 1280->1280 @8", 10, 8, 8, 1280, 1280),
     ("L3 2560->1280 @8", 10, 8, 8, 2560, 1280),
 ]
@@ -81,7 +84,8 @@ def bench_gemm(variants, rounds):
         out = torch.empty(M, nout, device=DEV, dtype=torch.float16)
         line = f"gemm {name:28s} {2.0 * M * N * K / 1e9:8.1f} GF |"
         for v in variants:
-            hip.set_igemm_variant(v)
+            hip.set_igemm_pingpong(v != -2)      # -2: the shape heuristic with the ping-pong kernel switched off
+            hip.set_igemm_variant(max(v, -1))
             d = hip.GemmDesc(M, N, K, K, nout, nout, epi, 1, 0, 1.0, 0)
             wsb = hip.gemm_workspace_bytes(d)
             ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
@@ -91,6 +95,7 @@ def bench_gemm(variants, rounds):
             line += f" v{v}: {med:7.1f}us {2.0 * M * N * K / med / 1e6:6.0f}TF |"
         print(line, flush=True)
     hip.set_igemm_variant(-1)
+    hip.set_igemm_pingpong(True)
 
 
 def bench_conv(variants, rounds):
@@ -102,7 +107,8 @@ def bench_conv(variants, rounds):
         fl = 2.0 * n * H * W * 9 * cin * cout
         line = f"conv {name:28s} {fl / 1e9:8.1f} GF |"
         for v in variants:
-            hip.set_igemm_variant(v)
+            hip.set_igemm_pingpong(v != -2)
+            hip.set_igemm_variant(max(v, -1))
             d = hip.ConvDesc(n, H, W, cin, cout, 1, 0, cin, cout, 0, 1, 1, 0, 1.0, 0)
             wsb = hip.conv3x3_workspace_bytes(d)
             ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
