@@ -11,7 +11,10 @@ in the data path (stories are independent: SURVEY §8e) -> weak scaling; value =
 Prints ONE JSON line (rank 0).  `roofline`: bound = mfma; one "launch" = one replay of the captured step graph
 (~1.4k kernels = one UNet call + CFG/DDIM); achieved = 11.044 TFLOP algorithmic (SURVEY §8d, 2*MAC of the
 reference's conv/addmm/mm/bmm/baddbmm at b=2,f=5,64x64,L=85) x S / the average replay duration measured with HIP
-events on the launch stream.  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
+events on the launch stream.  The two CFG halves of a step have identical inputs up to the first cross-attention
+(RCDMs_pipeline.py:481-482), so conv_in, the first ResNet block and the first self-attention are evaluated once and
+stored for both (0.33 of the 11.044 TFLOP; exact — config.shared_cfg_prefix, --no-share-prefix for the A/B); `achieved`
+still prices the reference's full 11.044 TFLOP per call.  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
 timed on this box's host cores on a bounded sample (a few UNet calls of the 50), extrapolated to T calls."""
 import argparse
 import json
@@ -108,6 +111,9 @@ def parse_args(argv=None):
     ap.add_argument("--guidance", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-share-prefix", action="store_true",
+                    help="evaluate the part of the UNet ahead of the first cross-attention for BOTH CFG halves (A/B switch; "
+                         "the default evaluates it once: the halves' inputs are identical there and the result is exact)")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="TEST ONLY: exercise the launch / barrier / max-over-ranks harness on CPU (gloo) with a sleep "
                          "in place of the denoising loop; the printed line is marked data=stub and is not a measurement")
@@ -237,7 +243,8 @@ def main(argv=None):
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
     S, T = a.stories, a.ddim_steps
     story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42 + rank)
-    loop = DenoiseLoop(model, S, 5, a.latent, a.latent, a.ctx_len, a.guidance, sched, T)
+    loop = DenoiseLoop(model, S, 5, a.latent, a.latent, a.ctx_len, a.guidance, sched, T,
+                       share_cfg_prefix=not a.no_share_prefix)
 
     def one_pass():
         loop.load(story["latents"], story["mask"], story["masked_latents"], story["ctx"])
@@ -283,7 +290,8 @@ def main(argv=None):
         "config": {"workload": f"{'FlintstonesSV' if a.ctx_len == 91 else 'PororoSV'} stage-2, {a.latent * 8}x{a.latent * 8}, "
                                f"{T}-step DDIM, CFG {a.guidance}, "
                                f"batch={S} story x 5 frames per GPU, ctx {a.ctx_len}x768, random-init 1276.9M-param UNet3D",
-                   "stories_per_gpu": S, "latent": a.latent, "ddim_steps": T, "parallelism": f"story-replicas x{world}"},
+                   "stories_per_gpu": S, "latent": a.latent, "ddim_steps": T, "parallelism": f"story-replicas x{world}",
+                   "shared_cfg_prefix": bool(loop.shared)},
         "per_rank_ms": [round(1e3 * x / a.steps, 3) for x in per_rank],
         "roofline": roof,
     }

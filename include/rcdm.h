@@ -64,6 +64,8 @@ typedef struct {
   int32_t ldt;                /* RCDM_EPI_ROWVEC: rowvec row stride (floats) */
   float out_scale;            /* out = epi(...) * out_scale   (1/output_scale_factor, resnet.py:210) */
   int32_t split_k;
+  int32_t dup_rows;           /* != 0: every output row m is ALSO stored at row m + dup_rows of `out` (the two CFG halves
+                               * of a step share everything before the first cross-attention: computed once, stored twice) */
 } rcdm_gemm_desc;
 
 size_t rcdm_gemm_workspace_bytes(const rcdm_gemm_desc* d);
@@ -105,6 +107,7 @@ typedef struct {
   int32_t split_k;
   int32_t pad_after_only; /* 0: padding 1 on every side (default).  1: zero rows/columns only AFTER the image —
                            * diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) then a stride-2 conv (VAE encoder) */
+  int32_t dup_rows;       /* as rcdm_gemm_desc.dup_rows */
 } rcdm_conv3x3_desc;
 
 size_t rcdm_conv3x3_workspace_bytes(const rcdm_conv3x3_desc* d);

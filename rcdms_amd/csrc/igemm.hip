@@ -81,6 +81,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n,
 #pragma unroll
   for (int e = 0; e < 8; ++e) o.e[e] = (f16)(v[e] * p.out_scale);
   *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
+  if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + oc + p.dup) = o.u;
 }
 
 // fma(f16 half `sel` of the dword h, s, c) in fp32: v_fma_mix_f32 converts the f16 source on the fly
@@ -457,6 +458,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
                     o.e[e] = (f16)(hv * gelu_f(gv) * sc);
                   }
                   *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
+                  if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + oc + p.dup) = o.u;
                 }
               }
           }
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
                     }
                   }
                   *(uint4*)(p.out + (size_t)m * p.ldc + pn) = o.u;
+                  if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + pn + p.dup) = o.u;
                 }
               }
           }
@@ -782,6 +785,7 @@ int check_common(const IgemmArgs& a) {
   if ((a.epi & RCDM_EPI_RESIDUAL) && (!a.res || (a.ldr & 7))) return RCDM_EINVAL;
   if ((a.epi & RCDM_EPI_GEGLU) && (a.N % 64)) return RCDM_ESHAPE;
   if ((a.epi & RCDM_EPI_GEGLU) && (a.epi & RCDM_EPI_GELU)) return RCDM_EINVAL;
+  if (a.dup < 0) return RCDM_EINVAL;
   // buffer-load offsets are 32-bit with 0x80000000 reserved as "out of range"
   const size_t in_rows = (a.Ktot == a.Cin) ? (size_t)a.M : (size_t)(a.M / (a.Ho * a.Wo)) * a.Hi * a.Wi;
   if (in_rows * (size_t)a.lda * 2 >= 0x7FFFFFFFull || (size_t)a.N * a.Ktot * 2 >= 0x7FFFFFFFull) return RCDM_ESHAPE;
@@ -889,6 +893,7 @@ void from_gemm(const rcdm_gemm_desc* d, IgemmArgs& a) {
   a.Hi = a.Wi = a.Ho = a.Wo = 1; a.stride = 1; a.up = 0; a.pad = 1;
   a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.ldt = d->ldt;
   a.rows_per_sample = d->rows_per_sample; a.epi = d->epilogue; a.out_scale = d->out_scale;
+  a.dup = (long long)d->dup_rows * d->ldc;
 }
 
 int from_conv(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
@@ -907,6 +912,7 @@ int from_conv(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
   a.M = d->n_img * a.Ho * a.Wo; a.N = d->c_out; a.Cin = d->c_in; a.Ktot = 9 * d->c_in;
   a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.ldt = d->ldt;
   a.rows_per_sample = d->rows_per_sample; a.epi = d->epilogue; a.out_scale = d->out_scale;
+  a.dup = (long long)d->dup_rows * d->ldc;
   return RCDM_OK;
 }
 

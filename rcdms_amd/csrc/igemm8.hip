@@ -406,6 +406,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
             for (int e = 0; e < 8; ++e)
               o.e[e] = (f16)(((float)hh[u].e[e] + bh[e]) * gelu_f((float)gg[u].e[e] + bg[e]) * sc);
             *(uint4*)(p.out + (size_t)m * p.ldc + oc0 + c * 8) = o.u;
+            if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + oc0 + c * 8 + p.dup) = o.u;
           }
         }
       }
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + (float)rr[u].e[e]) * sc);
             *(uint4*)(p.out + (size_t)m * p.ldc + n) = o.u;
+            if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + n + p.dup) = o.u;
           }
         }
       }

@@ -20,6 +20,7 @@ struct IgemmArgs {
   int lda, ldc, ldr, ldt, rows_per_sample;
   int epi;
   float out_scale;
+  long long dup;     // element offset of the second copy of every output row (0 = none): dup_rows * ldc
   int tilesM, tilesN, kc, nk, splits, nk_per_split;
   long long* trace;  // debug: per-block s_memtime stamps (rcdm_debug_set_igemm_trace), normally null
   int dbg;           // ping-pong loop switches: 8 = rotate the k order per block (RCDM_PP_ROTATE, default on)

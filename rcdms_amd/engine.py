@@ -48,6 +48,9 @@ class Rows:
     def cols(self, c0, c):
         return Rows(self.buf, self.off + c0, self.M, c, self.ld)
 
+    def rows(self, r0, n):
+        return Rows(self.buf, self.off + r0 * self.ld, n, self.C, self.ld)
+
 
 class Plan:
     """Ordered launch list + the buffers it touches."""
@@ -100,7 +103,7 @@ class Plan:
 # single-kernel emitters
 
 def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geglu=False, scale=1.0, split_k=0,
-              gelu=False):
+              gelu=False, dup_rows=0):
     """out[M][N or N/2] = epi(A[M][K] W[N][K]^T); rowvec = (tensor, elem_offset, ldt, rows_per_sample)."""
     epi = 0
     if bias is not None:
@@ -114,7 +117,7 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
     if gelu:
         epi |= hip.EPI_GELU
     d = hip.GemmDesc(A.M, N, K, A.ld, out.ld, residual.ld if residual is not None else 0, epi,
-                     rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k)
+                     rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k, dup_rows)
     wsb = hip.gemm_workspace_bytes(d)
     ws = plan.scratch("splitk_ws", max(wsb, 256))
     bptr = bias.data_ptr() if bias is not None else 0
@@ -129,7 +132,7 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
 
 
 def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=None, rowvec=None, residual=None,
-                 scale=1.0, split_k=0, pad_after_only=0):
+                 scale=1.0, split_k=0, pad_after_only=0, dup_rows=0):
     epi = 0
     if bias is not None:
         epi |= hip.EPI_BIAS
@@ -138,7 +141,7 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
     if residual is not None:
         epi |= hip.EPI_RESIDUAL
     d = hip.ConvDesc(n_img, H, W, cin, cout, stride, up, x.ld, out.ld, residual.ld if residual is not None else 0,
-                     epi, rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k, pad_after_only)
+                     epi, rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k, pad_after_only, dup_rows)
     wsb = hip.conv3x3_workspace_bytes(d)
     ws = plan.scratch("splitk_ws", max(wsb, 256))
     bptr = bias.data_ptr() if bias is not None else 0
@@ -354,7 +357,7 @@ class Geo:
         self.M = self.n_img * self.hw
 
 
-def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0):
+def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, dup_rows=0):
     """ResnetBlock3D.forward (src/models/resnet.py:182-212).  temb = (tensor [b][ldt] fp32, col offset, ldt)
     = this block's slice of the batched time_emb_proj(silu(emb)) table.  x may be a concat view."""
     g = geo
@@ -369,7 +372,8 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0):
     if w.shortcut is not None:
         res = plan.rows("res_sc", g.M, w.cout)
         emit_gemm(plan, x, w.shortcut, w.cout, w.cin, res, bias=w.sb)
-    emit_conv3x3(plan, a2, g.n_img, g.H, g.W, w.conv2, w.cout, w.cout, out, bias=w.cb2, residual=res, scale=out_scale)
+    emit_conv3x3(plan, a2, g.n_img, g.H, g.W, w.conv2, w.cout, w.cout, out, bias=w.cb2, residual=res, scale=out_scale,
+                 dup_rows=dup_rows)
 
 
 def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C):
@@ -380,23 +384,29 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C):
     emit_gemm(plan, gg, ff2, C, 4 * C, tok, bias=ff2_b, residual=tok)
 
 
-def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0):
+def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False):
     """BasicTransformerBlock.forward (src/models/attention.py:479-526) in place on tok [n_seq*Lq][C]:
-    h += attn1(LN1(h)); h += attn2(LN2(h), ctx); h += FF(LN3(h)).  ctx_kv: Rows [n_seq*L][2C] = [K | V] of the context."""
+    h += attn1(LN1(h)); h += attn2(LN2(h), ctx); h += FF(LN3(h)).  ctx_kv: Rows [n_seq*L][2C] = [K | V] of the context.
+    shared_half: the two halves of tok (the CFG halves of a denoising step) hold IDENTICAL rows on entry — everything up
+    to the query projection of the cross-attention is then computed on the first half only and stored to both."""
     C, M = w.C, n_seq * Lq
     d_head = C // heads
-    # self-attention over the Lq tokens of each sequence
-    emit_layernorm(plan, tok, w.ln[0][0], w.ln[0][1], a)
-    qkv = plan.rows("qkv", M, 3 * C)
-    emit_gemm(plan, a, w.qkv1, 3 * C, C, qkv, bias=w.qkv1_b)
+    ns, Ms, dup = n_seq, M, 0
+    if shared_half:
+        assert w.has_cross and n_seq % 2 == 0
+        ns, Ms, dup = n_seq // 2, M // 2, M // 2
     ao = plan.rows("attn_out", M, C)
-    emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), n_seq, heads, Lq, Lq, d_head, ao)
-    emit_gemm(plan, ao, w.o1, C, C, tok, bias=w.o1_b, residual=tok)
+    # self-attention over the Lq tokens of each sequence
+    emit_layernorm(plan, tok.rows(0, Ms), w.ln[0][0], w.ln[0][1], a.rows(0, Ms))
+    qkv = plan.rows("qkv", M, 3 * C).rows(0, Ms)
+    emit_gemm(plan, a.rows(0, Ms), w.qkv1, 3 * C, C, qkv, bias=w.qkv1_b)
+    emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), ns, heads, Lq, Lq, d_head, ao.rows(0, Ms))
+    emit_gemm(plan, ao.rows(0, Ms), w.o1, C, C, tok.rows(0, Ms), bias=w.o1_b, residual=tok.rows(0, Ms), dup_rows=dup)
     if w.has_cross:
         # cross-attention over the L context rows of that sequence
-        emit_layernorm(plan, tok, w.ln[1][0], w.ln[1][1], a)
+        emit_layernorm(plan, tok.rows(0, Ms), w.ln[1][0], w.ln[1][1], a.rows(0, Ms))
         qc = plan.rows("qkv", M, C)
-        emit_gemm(plan, a, w.q2, C, C, qc, bias=w.q2_b)
+        emit_gemm(plan, a.rows(0, Ms), w.q2, C, C, qc.rows(0, Ms), bias=w.q2_b, dup_rows=dup)
         emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), n_seq, heads, Lq, L, d_head, ao)
         emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok)
     if w.geglu:
@@ -408,15 +418,17 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0):
         emit_gemm(plan, hid, w.ff2, C, 4 * C, tok, bias=w.ff2_b, residual=tok)
 
 
-def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32):
+def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_half=False):
     """Transformer3DModel.forward + BasicTransformerBlock.forward (src/models/attention.py:318-365,479-526).
-    ctx_kv: Rows [n_img*L][2C] = [K | V] projections of the context for this site (computed per context)."""
+    ctx_kv: Rows [n_img*L][2C] = [K | V] projections of the context for this site (computed per context).
+    shared_half: see emit_basic_block (x holds identical halves; both halves of `out` are still written in full)."""
     g, C = geo, w.C
+    n_s, M_s = (g.n_img // 2, g.M // 2) if shared_half else (g.n_img, g.M)
     a = plan.rows("norm", g.M, C)
-    emit_groupnorm(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, False, a, groups)
+    emit_groupnorm(plan, x.rows(0, M_s), n_s, g.hw, w.gn_g, w.gn_b, 1e-6, False, a.rows(0, M_s), groups)
     tok = plan.rows("tok", g.M, C)
-    emit_gemm(plan, a, w.proj_in, C, C, tok, bias=w.proj_in_b)
-    emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L)
+    emit_gemm(plan, a.rows(0, M_s), w.proj_in, C, C, tok.rows(0, M_s), bias=w.proj_in_b)
+    emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half)
     emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
 
 
@@ -459,7 +471,14 @@ COUT_PAD = 8   # conv_out writes 4 channels + 4 zero columns (16-byte rows)
 class UNetProgram:
     """Static launch plan of one UNet3DConditionModel.forward for fixed (b, f, H, W, L)."""
 
-    def __init__(self, cfg, sd, b, frames, H, W, L, device):
+    def __init__(self, cfg, sd, b, frames, H, W, L, device, shared_prefix=False):
+        """shared_prefix: the caller guarantees that samples [0, b/2) and [b/2, b) of the input are IDENTICAL and differ
+        only in their context rows (the two CFG halves of a denoising step: RCDMs_pipeline.py:481 duplicates the latents,
+        mask and masked latents).  conv_in, the first ResNet block and the first transformer up to the cross-attention
+        query are then evaluated once and stored to both halves — bit-identical to evaluating the half batch twice."""
+        if shared_prefix and (b % 2 or cfg["down_block_types"][0] != "CrossAttnDownBlock3D"):
+            raise hip.RcdmError("shared_prefix needs an even batch and a cross-attention first block")
+        self.shared_prefix = bool(shared_prefix)
         if H % 8 or W % 8:
             raise hip.RcdmError(f"latent size {H}x{W} must be a multiple of 8 on the HIP path")
         self.cfg, self.b, self.f, self.H, self.W, self.L = cfg, b, frames, H, W, L
@@ -555,8 +574,13 @@ class UNetProgram:
         self.x_in = plan.rows("x_in", g0.M, CIN_PAD, unique=True)
         conv_in_w = pk.conv3x3("conv_in.weight", cin_pad=CIN_PAD)
         self.in_channels = sd["conv_in.weight"].shape[1]
-        emit_conv3x3(plan, self.x_in, g0.n_img, g0.H, g0.W, conv_in_w, CIN_PAD, boc[0], skip_view(0),
-                     bias=pk.vec("conv_in.bias"))
+        g0h = Geo(b // 2, frames, H, W) if shared_prefix else None
+        if shared_prefix:
+            emit_conv3x3(plan, self.x_in.rows(0, g0h.M), g0h.n_img, g0.H, g0.W, conv_in_w, CIN_PAD, boc[0],
+                         skip_view(0).rows(0, g0h.M), bias=pk.vec("conv_in.bias"), dup_rows=g0h.M)
+        else:
+            emit_conv3x3(plan, self.x_in, g0.n_img, g0.H, g0.W, conv_in_w, CIN_PAD, boc[0], skip_view(0),
+                         bias=pk.vec("conv_in.bias"))
 
         # ---- cross-attention context: per-site [K|V] buffers, filled by the context plan -------------
         ctx_dim = cfg["cross_attention_dim"]
@@ -566,18 +590,20 @@ class UNetProgram:
         self._ctx_plan = ctx_plan
         site = [0]
 
-        def transformer(p, x, geo, out):
+        def transformer(p, x, geo, out, shared_half=False):
             w = pack_transformer(pk, p)
             kv = plan.rows(f"ctx_kv{site[0]}", geo.n_img * L, 2 * w.C, unique=True)
             site[0] += 1
             emit_ctx_kv(ctx_plan, w, self.ctx16, kv)
-            emit_transformer(plan, w, x, geo, kv, L, heads, out, groups)
+            emit_transformer(plan, w, x, geo, kv, L, heads, out, groups, shared_half=shared_half)
 
         def motion(p, x, geo, out):
             emit_motion(plan, pack_motion(pk, p, n_attn), x, geo, mheads, out, groups)
 
-        def layer(pb, j, kind_attn, res, x, geo, final_out):
-            """resnet -> [transformer] -> [motion]; the LAST op writes final_out, the others ping-pong."""
+        def layer(pb, j, kind_attn, res, x, geo, final_out, shared=False):
+            """resnet -> [transformer] -> [motion]; the LAST op writes final_out, the others ping-pong.
+            shared: the first layer under shared_prefix — the ResNet block runs on the first half of the batch (its
+            GroupNorm statistics are per sample, its time-embedding row per sample: nothing crosses the halves)."""
             stages = ["r"] + (["t"] if kind_attn else []) + (["m"] if has_motion(res) else [])
             cur = x
             cout = sd[pb + f"resnets.{j}.conv1.weight"].shape[0]
@@ -585,9 +611,13 @@ class UNetProgram:
                 dst = final_out if si == len(stages) - 1 else plan.rows(f"blk{si % 2}", geo.M, cout)
                 if st == "r":
                     pr = pb + f"resnets.{j}."
-                    emit_resnet(plan, pack_resnet(pk, pr), cur, geo, temb_of(pr), dst, eps, groups)
+                    if shared:
+                        emit_resnet(plan, pack_resnet(pk, pr), cur.rows(0, g0h.M), g0h, temb_of(pr), dst.rows(0, g0h.M),
+                                    eps, groups, dup_rows=g0h.M)
+                    else:
+                        emit_resnet(plan, pack_resnet(pk, pr), cur, geo, temb_of(pr), dst, eps, groups)
                 elif st == "t":
-                    transformer(pb + f"attentions.{j}.", cur, geo, dst)
+                    transformer(pb + f"attentions.{j}.", cur, geo, dst, shared_half=shared)
                 else:
                     motion(pb + f"motion_modules.{j}.", cur, geo, dst)
                 cur = dst
@@ -598,7 +628,8 @@ class UNetProgram:
         for i, kind in enumerate(cfg["down_block_types"]):
             pb = f"down_blocks.{i}."
             for j in range(lpb):
-                cur = layer(pb, j, kind == "CrossAttnDownBlock3D", 2 ** i, cur, geos[i], skip_view(k))
+                cur = layer(pb, j, kind == "CrossAttnDownBlock3D", 2 ** i, cur, geos[i], skip_view(k),
+                            shared=shared_prefix and i == 0 and j == 0)
                 k += 1
             if i != nlev - 1:
                 dsw = pk.conv3x3(pb + "downsamplers.0.conv.weight")

@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("epilogue", C.c_int32), ("rows_per_sample", C.c_int32), ("ldt", C.c_int32),
-                ("out_scale", C.c_float), ("split_k", C.c_int32)]
+                ("out_scale", C.c_float), ("split_k", C.c_int32), ("dup_rows", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("c_in", C.c_int32), ("c_out", C.c_int32), ("stride", C.c_int32),
                 ("upsample", C.c_int32), ("lda", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("epilogue", C.c_int32), ("rows_per_sample", C.c_int32), ("ldt", C.c_int32),
-                ("out_scale", C.c_float), ("split_k", C.c_int32), ("pad_after_only", C.c_int32)]
+                ("out_scale", C.c_float), ("split_k", C.c_int32), ("pad_after_only", C.c_int32),
+                ("dup_rows", C.c_int32)]
 
 
 class GroupNormDesc(C.Structure):

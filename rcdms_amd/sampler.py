@@ -12,7 +12,8 @@ from .engine import CIN_PAD
 
 
 class DenoiseLoop:
-    def __init__(self, unet, stories, frames, height, width, ctx_len, guidance_scale, scheduler, num_steps):
+    def __init__(self, unet, stories, frames, height, width, ctx_len, guidance_scale, scheduler, num_steps,
+                 share_cfg_prefix=True):
         self.unet, self.S, self.f, self.H, self.W = unet, stories, frames, height, width
         self.gs = float(guidance_scale)
         self.reps = 2 if guidance_scale > 1.0 else 1
@@ -45,24 +46,54 @@ class DenoiseLoop:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.init_noise_sigma = float(getattr(scheduler, "init_noise_sigma", 1.0))
 
-        b = self.reps * stories
-        self.prog = unet.program(b, frames, height, width, ctx_len)
+        self.ctx_len = ctx_len
         S, R, f, H, W = stories, self.reps, frames, height, width
         self.lat = torch.zeros(S, 4, f, H, W, dtype=torch.float32, device=dev)
         self.mask = torch.zeros(R * S, 1, f, H, W, dtype=torch.float32, device=dev)
         self.masked = torch.zeros(R * S, 4, f, H, W, dtype=torch.float32, device=dev)
-        p = self.prog
-        self._pre = [
-            lambda: hip.load_timestep(self.ts_dev.data_ptr(), self.step_dev.data_ptr(), p.t_dev.data_ptr(), b),
-            lambda: hip.assemble_input(self.lat.data_ptr(), self.mask.data_ptr(), self.masked.data_ptr(), S, R, f, H, W,
-                                       p.x_in.ptr, p.x_in.ld, CIN_PAD),
-        ]
-        self._post = [
-            lambda: hip.cfg_ddim_step(p.eps_out.ptr, p.eps_out.ld, self.lat.data_ptr(), S, R, f, H, W, self.gs,
-                                      self.coef.data_ptr(), self.step_dev.data_ptr()),
-            lambda: hip.advance_step(self.step_dev.data_ptr()),
-        ]
-        self.graph = None
+        # Two launch plans, built on first use: the general one, and the "shared prefix" one for the case the reference
+        # pipeline always produces under CFG (RCDMs_pipeline.py:481-482: latents, mask and masked latents of the two
+        # halves are the same tensors) where the part of the UNet ahead of the first cross-attention is evaluated once.
+        self.share_allowed = share_cfg_prefix
+        self._variants = {}
+        self._v = None
+
+    def _select(self, share):
+        v = self._variants.get(share)
+        if v is None:
+            S, R, f, H, W = self.S, self.reps, self.f, self.H, self.W
+            b = R * S
+            p = self.unet.program(b, f, H, W, self.ctx_len, shared_prefix=share)
+            pre = [
+                lambda: hip.load_timestep(self.ts_dev.data_ptr(), self.step_dev.data_ptr(), p.t_dev.data_ptr(), b),
+                lambda: hip.assemble_input(self.lat.data_ptr(), self.mask.data_ptr(), self.masked.data_ptr(), S, R, f, H, W,
+                                           p.x_in.ptr, p.x_in.ld, CIN_PAD),
+            ]
+            post = [
+                lambda: hip.cfg_ddim_step(p.eps_out.ptr, p.eps_out.ld, self.lat.data_ptr(), S, R, f, H, W, self.gs,
+                                          self.coef.data_ptr(), self.step_dev.data_ptr()),
+                lambda: hip.advance_step(self.step_dev.data_ptr()),
+            ]
+            v = self._variants[share] = dict(prog=p, pre=pre, post=post, graph=None)
+        self.shared = share
+        self._v = v
+
+    def _cur(self):
+        if self._v is None:
+            self._select(False)
+        return self._v
+
+    prog = property(lambda self: self._cur()["prog"])
+    _pre = property(lambda self: self._cur()["pre"])
+    _post = property(lambda self: self._cur()["post"])
+
+    @property
+    def graph(self):
+        return self._cur()["graph"]
+
+    @graph.setter
+    def graph(self, g):
+        self._cur()["graph"] = g
 
     def _one_step_eager(self):
         for op in self._pre:
@@ -80,6 +111,10 @@ class DenoiseLoop:
         self.lat.copy_(latents.to(self.device, torch.float32) * self.init_noise_sigma)
         self.mask.copy_(mask.to(self.device, torch.float32))
         self.masked.copy_(masked_latents.to(self.device, torch.float32))
+        # the CFG halves share their UNet input exactly when mask and masked latents repeat (the latents always do)
+        share = (self.share_allowed and R == 2 and bool(torch.equal(self.mask[:S], self.mask[S:]))
+                 and bool(torch.equal(self.masked[:S], self.masked[S:])))
+        self._select(share)
         self.prog.set_context(ctx, force=True)   # ~3 MB + 16 small GEMMs per story: never trust a cache here
         self.step_dev.zero_()
         torch.cuda.current_stream(self.device).synchronize()

@@ -259,21 +259,22 @@ class UNet3DConditionModel(nn.Module):
             motion_attention_blocks=len(mk.get("attention_block_types", ("Temporal_Self", "Temporal_Self"))),
             mid_block_scale_factor=c.mid_block_scale_factor)
 
-    def program(self, b, frames, H, W, L):
-        """The cached static launch plan for one input geometry."""
+    def program(self, b, frames, H, W, L, shared_prefix=False):
+        """The cached static launch plan for one input geometry (shared_prefix: see rcdms_amd.engine.UNetProgram)."""
         dev = self.device
         if dev.type != "cuda":
             raise hip.RcdmError("UNet3DConditionModel runs on MI355X only: move the model to a CUDA/HIP device "
                                 "(rcdms_amd has no CPU fallback)")
         if self.config.motion_module_decoder_only and self.config.use_motion_module:
             raise NotImplementedError("motion_module_decoder_only is not supported on the HIP path")
-        key = (b, frames, H, W, L, str(dev))
+        key = (b, frames, H, W, L, str(dev), bool(shared_prefix))
         prog = self._programs.get(key)
         if prog is None:
             while len(self._programs) >= self.MAX_LIVE_PLANS:      # least recently used geometry goes first
                 self._programs.pop(next(iter(self._programs)))
             with torch.no_grad():
-                prog = engine.UNetProgram(self.engine_config(), self.state_dict(), b, frames, H, W, L, dev)
+                prog = engine.UNetProgram(self.engine_config(), self.state_dict(), b, frames, H, W, L, dev,
+                                          shared_prefix=shared_prefix)
         else:
             self._programs.pop(key)
         self._programs[key] = prog                                  # (re)insert as most recently used

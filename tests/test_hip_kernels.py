@@ -154,6 +154,27 @@ def test_gemm_pingpong(hiplib, M, N, K, epi, split, variant):
     assert torch.isnan(out[:, N:].float()).all(), "wrote outside the N columns"
 
 
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 8])
+@pytest.mark.parametrize("split", [1, 2])
+def test_gemm_dup_rows(hiplib, variant, split):
+    """rcdm_gemm_desc.dup_rows: every output row is also stored dup_rows further down (shared CFG prefix)."""
+    from rcdms_amd import hip
+    hip.set_igemm_variant(variant)
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 320, 256
+    A = h16(torch.randn(M, K, generator=g)); W = h16(torch.randn(N, K, generator=g) * K ** -0.5)
+    bias = torch.randn(N, generator=g)
+    Ad, Wd, bd = A.half().to(DEV), W.half().to(DEV), bias.to(DEV)
+    out = torch.full((2 * M + 3, N), float("nan"), dtype=torch.float16, device=DEV)
+    d = hip.GemmDesc(M, N, K, K, N, 0, 1, 1, 0, 1.0, split, M + 3)
+    w = ws(hip.gemm_workspace_bytes(d))
+    hip.gemm(d, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), 0, 0, out.data_ptr(), w.data_ptr(), w.numel())
+    torch.cuda.synchronize()
+    hip.set_igemm_variant(-1)
+    close(out[:M], A @ W.t() + bias)
+    assert torch.equal(out[:M], out[M + 3:]) and torch.isnan(out[M:M + 3].float()).all()
+
+
 @pytest.mark.parametrize("variant", [6, 7, 8])
 def test_gemm_pingpong_bitwise_vs_128(hiplib, variant):
     """Same k order inside a tile -> the ping-pong kernel and the 128x128 kernel agree BIT FOR BIT without split-K

@@ -247,3 +247,45 @@ def test_story_batch_equals_single_stories(hiplib):
         loop1.load(s2["latents"][i:i + 1], mask, ml, ctx)
         one = loop1.run().clone().cpu()
         check(both[i:i + 1], one, 3.5e-3, 5e-3, f"story {i} of a batch of 2 vs alone")
+
+
+def test_shared_cfg_prefix_matches_full_evaluation(hiplib):
+    """The shared-prefix plan (conv_in, first ResNet block and first self-attention evaluated once for the two CFG halves)
+    against the plan that evaluates both halves: same loop, same inputs.  The halves' prefix values are identical by
+    construction in both plans; the two plans may pick different tiles (M halves), so agreement is to f16 rounding, not
+    bitwise.  A story whose halves differ (different masked latents) must fall back to the full plan."""
+    from rcdms_amd.sampler import DenoiseLoop
+    from rcdms_amd.scheduler import DDIMScheduler
+    m = build("unet_tiny")
+    s = _tiny_story(2, seed=9)
+    mk = lambda: DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    outs = {}
+    for share in (True, False):
+        loop = DenoiseLoop(m, 2, 5, 16, 16, 13, 2.0, mk(), 3, share_cfg_prefix=share)
+        loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+        assert loop.shared is share
+        outs[share] = loop.run().clone()
+        if share:   # eager == graph on the shared plan too
+            loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+            assert torch.equal(outs[True], loop.run(use_graph=False))
+            ml = s["masked_latents"].clone()
+            ml[2:] += 0.1                                  # the cond half now sees different masked latents
+            loop.load(s["latents"], s["mask"], ml, s["ctx"])
+            assert loop.shared is False
+    check(outs[True], outs[False].float().cpu(), 2e-3, 4e-3, "shared CFG prefix vs both halves evaluated")
+
+
+def test_shared_cfg_prefix_full_width(full_unet):
+    """Same at the real width and size (64x64, 2 steps) — the trajectory tests above run the shared plan against the
+    reference; this one bounds its distance from the unshared plan."""
+    s = synth.synthetic_story(stories=1, latent_hw=(64, 64), ctx_len=85, seed=42)
+    outs = {}
+    for share in (True, False):
+        from rcdms_amd.sampler import DenoiseLoop
+        from rcdms_amd.scheduler import DDIMScheduler
+        sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+        loop = DenoiseLoop(full_unet, 1, 5, 64, 64, 85, 2.0, sched, 50, share_cfg_prefix=share)
+        loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+        assert loop.shared is share
+        outs[share] = loop.run(steps=2).clone()
+    check(outs[True], outs[False].float().cpu(), 2e-3, 4e-3, "shared CFG prefix vs both halves evaluated, full width")
