@@ -13,6 +13,7 @@
 // Its A operand (head-dim rows x keys) is read from the row-major V image with gfx950's LDS transpose read
 // (ds_read_b64_tr_b16), in the key order the S^T accumulator registers hold P, so V needs no transposing
 // scatter on the way in and no cross-lane shuffle on the way out.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -29,6 +30,7 @@ struct AttnArgs {
   float c;  // scale * log2(e)
   const unsigned char* kvalid;  // MASKED: [batch][Lk], 0 = key padded out (NULL = all valid)
   int causal;                   // MASKED: key k visible to query q only if k <= q
+  int plain_order;              // RCDM_ATTN_XCD=0: blocks in plain (query block fastest) order, for A/B
 };
 
 // V row stride in LDS (halfs) for 32*DF padded columns: the smallest >= 64*DF bytes whose dword stride is 16 or 48
@@ -54,12 +56,16 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // while the running max does not move, and all K/V staging index math hoisted out of the key-tile loop.
 // MASKED: causal and/or key-padding mask (the stage-1 prior transformer's additive -10000 mask, myprior_transformer.py:
 // 389-393: a masked score contributes exp(-10000) = 0 in fp32, so masking hard to -inf is the same result).
-template <int DS, int QF, bool PIPE, bool MASKED>  // d padded to 16*DS for QK^T and to 32*DF for PV; a wave owns QF fragments of 32 queries
-__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
+// NW waves per block (4: two blocks per CU; 8: one block of 256 queries per CU — every K/V tile is fetched from L2 and
+// staged once per 256 queries instead of once per 128: the self-attention of the 64x64 level re-reads 640 KB of K/V per
+// query block, 1.6 GB per launch through the ~13 TB/s L2 -> CU path).
+template <int DS, int QF, bool PIPE, bool MASKED, int NW>  // d padded to 16*DS for QK^T and to 32*DF for PV; a wave owns QF fragments of 32 queries
+__global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p) {
   constexpr int DF = (DS + 1) / 2;
   constexpr int KP = 16 * DS + 8;  // halfs per K row
-  constexpr int NSLOT = (KT * 2 * DS + 255) / 256;  // 16-B chunks a thread stages per tile (K and V each)
-  constexpr int BQ = 128 * QF;                      // queries per block
+  constexpr int NT = NW * 64;
+  constexpr int NSLOT = (KT * 2 * DS + NT - 1) / NT;  // 16-B chunks a thread stages per tile (K and V each)
+  constexpr int BQ = NW * 32 * QF;                  // queries per block
   constexpr int VR = v_row_halfs(DF);               // halfs per V row
   constexpr int SK = KT * KP, SV = KT * VR;         // halfs per K / V image; two of each (ping-pong)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,13 +74,26 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * BQ + wave * 32 * QF + lr;  // fragment j holds query q0 + 32 j
+  // XCD-aware block order: block `lin` runs on XCD lin % 8 (each XCD has its own 4 MB L2), so every XCD is given a
+  // contiguous run of the (batch, head, query block) sequence with the query block fastest — the 32 query blocks that
+  // stream the same 640 KB of K/V then hit ONE L2 instead of pulling a copy into all eight (rocprofv3 FETCH_SIZE of the
+  // 64x64 self-attention: 8x the K/V bytes with the plain order).
+  const int nqb = (p.Lq + BQ - 1) / BQ;
+  int item;
+  {
+    const int total = nqb * p.heads * p.batch, lin = blockIdx.x;
+    const int xcd = lin & 7, q = total >> 3, r = total & 7;
+    item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    if (p.plain_order) item = lin;
+  }
+  const int qb = item % nqb, bh = item / nqb;
+  const int h = bh % p.heads, b = bh / p.heads;
+  const int q0 = qb * BQ + wave * 32 * QF + lr;  // fragment j holds query q0 + 32 j
   // a spare V column exists: column d := 1 gives sum_k P[k][q] for free.  Always true for odd DS (d <= 16 DS < 32 DF).
   const bool ones_row = (DS & 1) ? true : p.d < 32 * DF;
 
   // zero the LDS images once: the pad columns of K and V stay zero afterwards
-  for (int i = t; i < (2 * SK + 2 * SV) / 8; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = t; i < (2 * SK + 2 * SV) / 8; i += NT) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   if (ones_row && t < 2 * KT) sV[(t >> 6) * SV + (t & 63) * VR + p.d] = (f16)1.0f;
 
@@ -121,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
   bool s_ok[NSLOT];
 #pragma unroll
   for (int sl = 0; sl < NSLOT; ++sl) {
-    const int idx = t + 256 * sl;
+    const int idx = t + NT * sl;
     s_ok[sl] = idx < nchunks;
     const int key = idx / p.dch, c = idx - key * p.dch;  // chunk fastest: contiguous in HBM and in LDS
     k_lds[sl] = key * KP + c * 8;
@@ -309,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
     } else {
       l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
     }
-    const float inv = 1.f / l_tot;
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;  // MASKED: a query with no visible key gives 0, not NaN
     const int q = q0 + 32 * j;
     if (q < p.Lq) {
       f16* ob = p.O + ((size_t)b * p.Lq + q) * p.ldo + h * p.d;
@@ -329,15 +348,36 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnArgs p) {
 }
 
 template <int DS>
-int launch_flash(const AttnArgs& a, hipStream_t stream) {
+int launch_flash(const AttnArgs& a_in, hipStream_t stream) {
   constexpr int DF = (DS + 1) / 2;
   constexpr int KP = 16 * DS + 8;
   const size_t lds = (size_t)2 * (KT * KP + KT * v_row_halfs(DF)) * sizeof(f16);  // ping-pong K and V images
-  dim3 grid((a.Lq + 127) / 128, a.heads, a.batch);
-  if (a.kvalid || a.causal)
-    hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), true>), grid, dim3(256), lds, stream, a);
-  else
-    hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), false>), grid, dim3(256), lds, stream, a);
+  static int nw_mode = -1;  // RCDM_ATTN_WAVES=4|8 forces the block size (A/B switch); default by shape
+  if (nw_mode < 0) {
+    const char* e = getenv("RCDM_ATTN_WAVES");
+    nw_mode = e ? atoi(e) : 0;
+  }
+  // 256-query blocks when there are enough of them to fill the chip and many key tiles to share
+  // measured (tools/kbench.py attn, RCDM_ATTN_WAVES=4|8): 256-query blocks are 3-30 % SLOWER on every shape (the K/V
+  // stream is not what binds; an 8-wave barrier per key tile costs more), so 8 is only ever taken when forced
+  const bool big = nw_mode == 8;
+  static int xcd_mode = -1;
+  if (xcd_mode < 0) {
+    const char* e = getenv("RCDM_ATTN_XCD");
+    xcd_mode = e ? atoi(e) : 1;
+  }
+  AttnArgs a = a_in;
+  a.plain_order = xcd_mode ? 0 : 1;
+  if (a.kvalid || a.causal) {
+    dim3 grid(((a.Lq + 127) / 128) * a.heads * a.batch);
+    hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), true, 4>), grid, dim3(256), lds, stream, a);
+  } else if (big) {
+    dim3 grid(((a.Lq + 255) / 256) * a.heads * a.batch);
+    hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), false, 8>), grid, dim3(512), lds, stream, a);
+  } else {
+    dim3 grid(((a.Lq + 127) / 128) * a.heads * a.batch);
+    hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), false, 4>), grid, dim3(256), lds, stream, a);
+  }
   return rcdm_check_launch();
 }
 
