@@ -34,37 +34,19 @@
 // vmcnt immediates wave-dependent: picked by a wave-uniform branch.
 #include "common.h"
 #include "igemm_args.h"
+#include "pp_sync.h"
 
 const PPShape kPPShapes[kNumPPShapes] = {{160, 320}, {160, 256}, {256, 256}};
 
+// cache policy of the two LDS-DMA streams (buffer_load ... lds aux bits: 1 = sc0, 2 = nt, 16 = sc1); experiments only
+#ifndef RCDM_PP_AAUX
+#define RCDM_PP_AAUX 0
+#endif
+#ifndef RCDM_PP_WAUX
+#define RCDM_PP_WAUX 0
+#endif
+
 namespace {
-
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void tick_barrier() {
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform runtime n in [0, 12]
-__device__ __forceinline__ void wait_vm_n(int n) {
-  switch (n) {
-    case 0: wait_vm<0>(); break;
-    case 1: wait_vm<1>(); break;
-    case 2: wait_vm<2>(); break;
-    case 3: wait_vm<3>(); break;
-    case 4: wait_vm<4>(); break;
-    case 5: wait_vm<5>(); break;
-    case 6: wait_vm<6>(); break;
-    case 7: wait_vm<7>(); break;
-    case 8: wait_vm<8>(); break;
-    case 9: wait_vm<9>(); break;
-    case 10: wait_vm<10>(); break;
-    case 11: wait_vm<11>(); break;
-    default: wait_vm<12>(); break;
-  }
-}
 
 template <int TAPS, int FMW, int FNW, bool SLAB>
 __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
@@ -186,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
       }
       if (a_lds[i] >= 0)  // wave-uniform: the waves whose last piece does not exist issue one DMA fewer
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrcA, (__attribute__((address_space(3))) void*)(smem + slot * A_BYTES + a_lds[i]), 16, vo, 0, 0, 0);
+            rsrcA, (__attribute__((address_space(3))) void*)(smem + slot * A_BYTES + a_lds[i]), 16, vo, 0, 0, RCDM_PP_AAUX);
     }
   };
   auto issue_w = [&](int ks) __attribute__((always_inline)) {
@@ -199,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
       const unsigned vo = (c < p.Cin && w_off[i] != OOB)
                               ? w_off[i] + ((unsigned)tap * (unsigned)p.Cin + (unsigned)c) * 2u : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrcW, (__attribute__((address_space(3))) void*)(smem + slot * W_BYTES + w_lds[i]), 16, vo, 0, 0, 0);
+          rsrcW, (__attribute__((address_space(3))) void*)(smem + slot * W_BYTES + w_lds[i]), 16, vo, 0, 0, RCDM_PP_WAUX);
     }
   };
 
@@ -220,6 +202,13 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
   constexpr bool no_dma = (RCDM_PP_ABLATE & 1) != 0, no_mfma = (RCDM_PP_ABLATE & 2) != 0, no_read = (RCDM_PP_ABLATE & 4) != 0;
 #else
   constexpr bool no_dma = false, no_mfma = false, no_read = false;
+#endif
+  // RCDM_PP_ISSUE_FIRST: the DMA pieces of an L phase are issued BEFORE its ds_reads (the issue stalls on the
+  // vector-memory queue; reads queued behind it complete under that stall instead of in front of it)
+#ifdef RCDM_PP_ISSUE_FIRST
+  constexpr bool issue_first = true;
+#else
+  constexpr bool issue_first = false;
 #endif
   auto load_frags = [&](int aslot, int wslot, int koff) __attribute__((always_inline)) {
     if (no_read) return;
@@ -274,23 +263,31 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
       const int aslot = g & 1;
       // tick 4g: L(g,0).  Group 1 reads its pixel rows of THIS k-step one tick from now (issued in tick 4g-4): all but
       // the newest pixel part and the weight part before it must have landed.
-      load_frags(aslot, wslot, koff0);
-      if (g + 1 < nkl && !no_dma) {
-        issue_px(g + 1);
-        wait_lgkm0();
-        wait_vm_n(keep);
+      const bool more_p0 = g + 1 < nkl && !no_dma;
+      if (issue_first) {
+        if (more_p0) issue_px(g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(aslot, wslot, koff0);
       } else {
-        wait_lgkm0();
-        wait_vm<0>();
+        load_frags(aslot, wslot, koff0);
+        if (more_p0) issue_px(g + 1);
       }
+      wait_lgkm0();
+      if (more_p0) wait_vm_n(keep); else wait_vm<0>();
       tick_barrier();
       // tick 4g+1: C(g,0)
       compute();
       tick_barrier();
       // tick 4g+2: L(g,1): the weight tile of k-step g-1 is free since tick 4g-1 -> lower half of k-step g+2
-      load_frags(aslot, wslot, koff1);
       const bool more_w = g + 2 < nkl && !no_dma;
-      if (more_w) issue_w(g + 2);
+      if (issue_first) {
+        if (more_w) issue_w(g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(aslot, wslot, koff1);
+      } else {
+        load_frags(aslot, wslot, koff1);
+        if (more_w) issue_w(g + 2);
+      }
       wait_lgkm0();
       tick_barrier();
       // tick 4g+3: C(g,1); the lower weight rows of k-step g+1 (issued in tick 4g-2) must have landed
@@ -307,8 +304,14 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
       const int aslot = g & 1;
       const bool more = g + 2 < nkl && !no_dma;
       // tick 4g+1: L(g,0): upper half of the weight rows of k-step g+2
-      load_frags(aslot, wslot, koff0);
-      if (more) issue_w(g + 2);
+      if (issue_first) {
+        if (more) issue_w(g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(aslot, wslot, koff0);
+      } else {
+        load_frags(aslot, wslot, koff0);
+        if (more) issue_w(g + 2);
+      }
       wait_lgkm0();
       tick_barrier();
       // tick 4g+2: C(g,0)
@@ -316,15 +319,16 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
       tick_barrier();
       // tick 4g+3: L(g,1); group 0 finished with its pixel rows of k-step g one tick ago -> refill them for g+2;
       // its pixel rows and the upper weight rows of k-step g+1 must have landed
-      load_frags(aslot, wslot, koff1);
-      if (more) {
-        issue_px(g + 2);
-        wait_lgkm0();
-        wait_vm_n(keep);
+      if (issue_first) {
+        if (more) issue_px(g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(aslot, wslot, koff1);
       } else {
-        wait_lgkm0();
-        wait_vm<0>();
+        load_frags(aslot, wslot, koff1);
+        if (more) issue_px(g + 2);
       }
+      wait_lgkm0();
+      if (more) wait_vm_n(keep); else wait_vm<0>();
       tick_barrier();
       // tick 4g+4: C(g,1)
       compute();
