@@ -13,7 +13,7 @@ Prints ONE JSON line (rank 0).  `roofline`: bound = mfma; one "launch" = one rep
 reference's conv/addmm/mm/bmm/baddbmm at b=2,f=5,64x64,L=85) x S / the average replay duration measured with HIP
 events on the launch stream.  The two CFG halves of a step have identical inputs up to the first cross-attention
 (RCDMs_pipeline.py:481-482), so conv_in, the first ResNet block and the first self-attention are evaluated once and
-stored for both (0.33 of the 11.044 TFLOP; exact — config.shared_cfg_prefix, --no-share-prefix for the A/B); `achieved`
+stored for both (0.21 of the 11.044 TFLOP; exact — config.shared_cfg_prefix, --no-share-prefix for the A/B); `achieved`
 still prices the reference's full 11.044 TFLOP per call.  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
 timed on this box's host cores on a bounded sample (a few UNet calls of the 50), extrapolated to T calls."""
 import argparse
