@@ -151,7 +151,7 @@ def test_full_unet_flintstones_batch4(full_unet, hw):
 # Measured on MI355X (32x32, 20 steps): drift 5.1e-4 after step 1, 8.2e-4 after step 20 (it saturates: with random-init
 # weights |x| grows ~20x, so late steps add little RELATIVE error); one step from a reference x_k: 3.7e-4 (k=1) falling
 # to 2e-6 (k=19).  Tolerances are <= 2.2x those numbers.
-LOOP_TOL = {32: dict(step=1e-3, end=1.8e-3), 64: dict(step=1.2e-3, end=2.5e-3)}
+LOOP_TOL = {32: dict(step=1e-3, end=1.8e-3), 64: dict(step=5e-4, end=1.5e-3)}
 
 
 def _full_loop(full_unet, hw, steps):
