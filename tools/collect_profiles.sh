@@ -14,4 +14,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c -d "$out/pmc_$c" -o p -- python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline --no-graph > "$out/pmc_$c.log" 2>&1
 done
 python tools/hbm_traffic.py "$out" 2 < /dev/null > "$out/hbm_traffic.json"
+rm -rf "$out/trace" "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE   # raw rocpd databases: tens of MB, summaries are kept
 head -30 "$out/kernel_stats.txt"; cat "$out/hbm_traffic.json"

@@ -15,4 +15,5 @@ for set in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
   timeout 300 rocprofv3 --pmc $set -d "$out/p$i" -o p -- python tools/kbench.py "$@" --rounds 1 > "$out/p$i.log" 2>&1 < /dev/null
 done
 python tools/pmc_summary.py "$out" < /dev/null > "$out/pmc.txt"
+rm -rf "$out"/p[0-9]   # raw rocpd databases
 cat "$out/pmc.txt"
