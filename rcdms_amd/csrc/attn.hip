@@ -542,7 +542,14 @@ int rcdm_temporal_attn(const rcdm_temporal_attn_desc* d, const void* qkv, void* 
   a.heads = d->heads; a.d = d->d; a.ldqkv = d->ldqkv; a.ldo = d->ldo; a.scale = d->scale;
   const int C = d->heads * d->d;
   const size_t px_bytes = (size_t)d->frames * 3 * C * sizeof(f16);   // LDS per pixel
-  int tpb = (int)((60 * 1024) / px_bytes);                            // ~60 KB: two blocks per CU
+  // measured (tools/kbench.py attn --only temporal): 32 KB blocks run the 64x64 / 32x32 levels at 4.1 / 3.5 TB/s, 60 KB
+  // blocks (two per CU) at 2.9 / 2.5 — the three phases (stage, compute, store) of a block do not overlap, more blocks do
+  static int lds_cap_kb = -1;  // RCDM_TATTN_KB: LDS per block (A/B switch)
+  if (lds_cap_kb < 0) {
+    const char* e = getenv("RCDM_TATTN_KB");
+    lds_cap_kb = e ? atoi(e) : 32;
+  }
+  int tpb = (int)(((size_t)lds_cap_kb * 1024) / px_bytes);
   const int by_threads = 256 / (d->heads * d->frames);
   if (tpb > by_threads) tpb = by_threads;
   if (tpb < 1) tpb = 1;
