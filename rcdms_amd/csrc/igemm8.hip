@@ -221,12 +221,16 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
   };
   auto compute = [&]() __attribute__((always_inline)) {
     if (no_mfma) return;
+#ifndef RCDM_PP_NOPRIO
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int i = 0; i < FNW; ++i)
 #pragma unroll
       for (int j = 0; j < FMW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#ifndef RCDM_PP_NOPRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // DMAs this wave has in flight when "its newest pixel part + its newest weight part" are outstanding
@@ -371,7 +375,11 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
     wait_lgkm0();
     tick_barrier();
     const float sc = p.out_scale;
-    constexpr int U = 4;
+#ifdef RCDM_PP_EPI_U
+    constexpr int U = RCDM_PP_EPI_U;
+#else
+    constexpr int U = 8;  // staged reads / residual loads in flight per thread (measured: 8 is 1-2 % faster than 4 on the 64x64 convs)
+#endif
     if (p.epi & RCDM_EPI_GEGLU) {
       constexpr int CPR = BN / 16;  // output chunks (8 hidden columns) per row
       constexpr int ITEMS = BM * CPR;
