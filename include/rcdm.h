@@ -41,7 +41,7 @@ extern "C" {
 #define RCDM_EPI_GELU 16     /* out = gelu(acc + bias + rowvec) (+ residual): exact erf GELU, the "gelu" FeedForward of
                              * the stage-1 prior (diffusers GELU(approximate="none")); not with GEGLU  */
 #define RCDM_EPI_GEGLU 8     /* out[m][j] = (h+bh) * gelu(g+bg); W/bias rows packed in groups of   */
-                             /* 64 = 32 hidden rows then their 32 gate rows (rcdm_pack_geglu_rows) */
+                             /* 32 = 16 hidden rows then their 16 gate rows (rcdm_pack_geglu_rows) */
 
 int rcdm_version(void);
 /* last HIP error code seen by this library on this thread (0 = none) and its string */
@@ -267,8 +267,8 @@ int rcdm_advance_step(int32_t* step_counter, void* stream);
  *   rcdm_pack_f16: elementwise fp32 -> f16.
  *   rcdm_pack_conv3x3: torch (Cout,Cin,3,3) fp32 -> f16 [Cout][9*cin_pad], k = tap*cin_pad + c.
  *   rcdm_pack_geglu_rows: FeedForward.net.0.proj weight (8C,K)/bias(8C) -> rows reordered so every
- *   64-row group holds 32 "hidden" rows then the matching 32 "gate" rows (RCDM_EPI_GEGLU): the two
- *   land in adjacent MFMA fragments of the same lane.
+ *   32-row group holds 16 "hidden" rows then the matching 16 "gate" rows (RCDM_EPI_GEGLU): the two
+ *   land in the same lane of the 16x16x32 and of the 32x32x16 MFMA accumulator layouts.
  * ---------------------------------------------------------------------------------------------- */
 int rcdm_pack_f16(const float* src, void* dst, size_t n, void* stream);
 int rcdm_pack_conv3x3(const float* w, int32_t c_out, int32_t c_in, int32_t cin_pad, void* dst,

@@ -31,7 +31,7 @@
 
 namespace {
 
-// v: 8 accumulated values of row m at packed columns n..n+7 (GEGLU: g = the matching gate columns n+32..).
+// v: 8 accumulated values of row m at packed columns n..n+7 (GEGLU: g = the matching gate columns n+16..).
 // n is a multiple of 8, so every per-column vector (bias, row vector) is fetched as two aligned float4.
 __device__ __forceinline__ void load8(const float* src, float (&d)[8]) {
   const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
@@ -45,7 +45,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n,
     if (p.epi & RCDM_EPI_BIAS) {
       float bh[8], bg[8];
       load8(p.bias + n, bh);
-      load8(p.bias + n + 32, bg);
+      load8(p.bias + n + kGegluGroup, bg);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         v[e] += bh[e];
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
       static_assert(NT % P_TPR == 0 && RPH % P_RPI == 0 && NT % G_TPR == 0 && RPH % G_RPI == 0, "epilogue sweep");
       const int pc8 = t % P_TPR, pr0 = t / P_TPR;
       const int oc8 = t % G_TPR, gr0 = t / G_TPR;
-      const int hc = (oc8 >> 2) * 8 + (oc8 & 3);  // GEGLU: 16-B chunk (8 halfs) of the hidden columns; the gate is 4 chunks on
+      const int hc = (oc8 >> 1) * 4 + (oc8 & 1);  // GEGLU: 16-B chunk (8 halfs) of the hidden columns; the gate is 2 chunks on
       const int pn = geglu ? cn0 + hc * 8 : cn0 + pc8 * 8;   // first packed column this thread handles
       const bool pn_ok = pn < p.N;
       constexpr bool WHOLE = NPASS * P_ITEMS <= 8;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
       for (int e = 0; e < 8; ++e) bA[e] = bB[e] = rvA[e] = rvB[e] = 0.f;
       if ((p.epi & RCDM_EPI_BIAS) && pn_ok) {
         load8(p.bias + pn, bA);
-        if (geglu) load8(p.bias + pn + 32, bB);
+        if (geglu) load8(p.bias + pn + kGegluGroup, bB);
       }
       if (rv_pair && pn_ok) {
         load8(p.rowvec + (size_t)smp0 * p.ldt + pn, rvA);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
                 const int row = gr0 + (it0 + k) * G_RPI;
                 const int sx = (row >> 1) & 7;
                 hh[k].u = *(const uint4*)(sH + row * BN_ + ((hc ^ sx) << 3));
-                gg[k].u = *(const uint4*)(sH + row * BN_ + (((hc + 4) ^ sx) << 3));
+                gg[k].u = *(const uint4*)(sH + row * BN_ + (((hc + 2) ^ sx) << 3));
               }
 #pragma unroll
             for (int k = 0; k < RCH; ++k)
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
        idx += (size_t)gridDim.x * blockDim.x) {
     const int m = (int)(idx / nout8);
     const int oc = (int)(idx - (size_t)m * nout8) * 8;
-    const int n = geglu ? (oc >> 5) * 64 + (oc & 31) : oc;
+    const int n = geglu ? (oc >> 4) * 32 + (oc & 15) : oc;
     float v[8], g[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = g[e] = 0.f;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
         v[4 + e] += b[e];
       }
       if (geglu) {
-        const f32x4 c = *(const f32x4*)(src + 32), d = *(const f32x4*)(src + 36);
+        const f32x4 c = *(const f32x4*)(src + kGegluGroup), d = *(const f32x4*)(src + kGegluGroup + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           g[e] += c[e];
@@ -633,12 +633,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
 }
 
 // variant: 1 = 128x128 (2 blocks/CU), 2 = 256x256 (1), 3 = 64x64 two-slot ring (4), 4 = 64x64 four-slot ring (2),
-// 5 = 128x64 (3); 6 / 7 / 8 = the ping-pong kernel of igemm8.hip at 160x320 / 160x256 / 256x256   (-1 = heuristic)
+// 5 = 128x64 (3); 6 / 7 / 8 = the ping-pong kernel of igemm8.hip at 160x320 / 160x256 / 256x256; 9 = the 160x160 kernel of
+// igemm16.hip (2)   (-1 = heuristic)
 int g_force_variant = -1;
 struct TileCfg { int bm, bn, blocks_per_cu; };
 constexpr int kFirstPP = 6;
-const TileCfg kTiles[9] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}, {64, 64, 4}, {64, 64, 2}, {128, 64, 3},
-                           {160, 320, 1}, {160, 256, 1}, {256, 256, 1}};
+constexpr int kVar16 = 9;  // igemm16.hip: 160x160, two blocks per CU
+const TileCfg kTiles[10] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}, {64, 64, 4}, {64, 64, 2}, {128, 64, 3},
+                            {160, 320, 1}, {160, 256, 1}, {256, 256, 1}, {160, 160, 2}};
 int g_pp_mode = -1;  // RCDM_PP=0: never pick the ping-pong kernel (A/B switch)
 int g_num_cus = 0;
 long long* g_trace = nullptr;
@@ -700,6 +702,24 @@ int pick_pp(const IgemmArgs& a) {
   return best;
 }
 
+// The 160x160 two-blocks-per-CU kernel (igemm16.hip), measured against every other variant (tools/kbench.py,
+// profiles/r2_kbench.txt): it wins on the wide-N GEMMs with K <= 1280 and >= 2560 rows — fused [q;k;v] and GEGLU
+// projections of the 64x64 / 32x32 / 16x16 levels: 7-15 % (no padded columns at N = 960 / 1920, 20 % fewer operand bytes
+// per flop than 128x128, and unlike the ping-pong kernel its epilogue hides under the CU's other block) — and on the convs
+// of the 32x32 level (3 % over the ping-pong kernel, which needs split-K there).  N = C GEMMs (HBM-bound or too few
+// tiles), K >= 2560 (split-K shapes) and the 8x8 level stay where they were.
+bool pick_16(const IgemmArgs& a) {
+  static int mode = -1;  // RCDM_I16=0: never (A/B switch)
+  if (mode < 0) {
+    const char* e = getenv("RCDM_I16");
+    mode = e ? atoi(e) : 1;
+  }
+  if (!mode) return false;
+  const int taps = a.Ktot / a.Cin;
+  if (taps == 1) return a.N >= 960 && a.N >= 2 * a.Cin && a.M >= 2048 && a.Cin <= 1280;  // wide N only: qkv (3C), GEGLU (8C)
+  return a.M >= 5120 && a.M < 20480 && a.N >= 640 && a.N <= 1280;
+}
+
 int pick_variant(const IgemmArgs& a) {
   if (g_force_variant < 0) {
     const char* e = getenv("RCDM_IGEMM");
@@ -714,6 +734,7 @@ int pick_variant(const IgemmArgs& a) {
     g_pp_mode = e ? atoi(e) : 1;
   }
   if (g_pp_mode) {
+    if (pick_16(a)) return kVar16;
     const int pp = pick_pp(a);
     if (pp >= 0) return kFirstPP + pp;
   }
@@ -764,7 +785,7 @@ int fill_common(IgemmArgs& a, int requested_split, int* variant_out = nullptr) {
   const int taps = a.Ktot / a.Cin;
   a.nk = taps * a.kc;
   int s;
-  if (variant >= kFirstPP && requested_split <= 0) {
+  if (variant >= kFirstPP && variant < kVar16 && requested_split <= 0) {
     const int tiles = a.tilesM * a.tilesN;
     s = tiles < num_cus() ? pp_splits(tiles, a.nk) : 1;
   } else {
@@ -783,7 +804,7 @@ int check_common(const IgemmArgs& a) {
   if ((a.epi & RCDM_EPI_BIAS) && !a.bias) return RCDM_EINVAL;
   if ((a.epi & RCDM_EPI_ROWVEC) && (!a.rowvec || a.rows_per_sample <= 0 || (a.ldt & 3))) return RCDM_EINVAL;
   if ((a.epi & RCDM_EPI_RESIDUAL) && (!a.res || (a.ldr & 7))) return RCDM_EINVAL;
-  if ((a.epi & RCDM_EPI_GEGLU) && (a.N % 64)) return RCDM_ESHAPE;
+  if ((a.epi & RCDM_EPI_GEGLU) && (a.N % 32)) return RCDM_ESHAPE;
   if ((a.epi & RCDM_EPI_GEGLU) && (a.epi & RCDM_EPI_GELU)) return RCDM_EINVAL;
   if (a.dup < 0) return RCDM_EINVAL;
   // buffer-load offsets are 32-bit with 0x80000000 reserved as "out of range"
@@ -827,6 +848,19 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   }
   a.trace = g_trace;
   a.dbg = 0;
+  if (variant == kVar16) {
+    int rc = rcdm_igemm16_launch(a, TAPS, stream);
+    if (rc) return rc;
+    if (a.splits > 1) {
+      const bool geglu = (a.epi & RCDM_EPI_GEGLU) != 0;
+      const size_t total = (size_t)a.M * ((geglu ? a.N / 2 : a.N) / 8);
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+      rc = rcdm_check_launch();
+    }
+    return rc;
+  }
   if (variant >= kFirstPP) {
     static int rotate = -1;
     if (rotate < 0) {
@@ -921,7 +955,7 @@ int from_conv(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
 extern "C" {
 
 int rcdm_set_igemm_variant(int32_t v) {
-  if (v < -1 || v > 8) return RCDM_EINVAL;
+  if (v < -1 || v > 9) return RCDM_EINVAL;
   g_force_variant = v < 0 ? 99 : v;
   return RCDM_OK;
 }

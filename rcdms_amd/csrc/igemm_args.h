@@ -26,13 +26,18 @@ struct IgemmArgs {
   int dbg;           // ping-pong loop switches: 8 = rotate the k order per block (RCDM_PP_ROTATE, default on)
 };
 
-// GEGLU packing (rcdm_pack_geglu_rows): packed rows/columns come in groups of 64 = 32 "hidden" + their 32 "gate";
-// packed column n of a hidden value <-> output column (n>>6)*32 + (n&31); its gate sits at n + 32.
-__host__ __device__ __forceinline__ int geglu_out_col(int n) { return (n >> 6) * 32 + (n & 31); }
+// GEGLU packing (rcdm_pack_geglu_rows): packed rows/columns come in groups of 32 = 16 "hidden" + their 16 "gate"
+// (16 = one 16x16x32 fragment, half a 32x32x16 one: value and gate sit in the same lane for both MFMA shapes, and every
+// tile width that is a multiple of 32 — 128, 160, 256, 320 — holds whole groups);
+// packed column n of a hidden value <-> output column (n>>5)*16 + (n&15); its gate sits at n + 16.
+constexpr int kGegluGroup = 16;
+__host__ __device__ __forceinline__ int geglu_out_col(int n) { return (n >> 5) * 16 + (n & 15); }
 
 // igemm8.hip: ping-pong tile shapes (index into kPPShapes), launched by igemm.hip's dispatcher
 struct PPShape { int bm, bn; };
 constexpr int kNumPPShapes = 3;
 extern const PPShape kPPShapes[kNumPPShapes];
+// igemm16.hip: 160x160 tiles, 4 waves, two blocks per CU
+int rcdm_igemm16_launch(const IgemmArgs& a, int taps, hipStream_t stream);
 // taps = 1 | 9; a.tilesM/tilesN/splits/nk_per_split/partial already planned for the shape.  Returns an RCDM_* code.
 int rcdm_igemm_pp_launch(const IgemmArgs& a, int taps, int shape, hipStream_t stream);

@@ -1,0 +1,150 @@
+// igemm_epilogue.h — tile epilogue shared by the phase-structured implicit-GEMM kernels (igemm8.hip: 8 waves,
+// igemm16.hip: 4 waves).  Called when every wave of the block is past its k-loop: no LDS read and no DMA is outstanding,
+// so the whole dynamic LDS is free for staging.
+// Accumulator layout (v_mfma_f32_16x16x32_f16, weights = A operand): acc[i][j][e] = D[channel col0 + 16 i + 4 kg + e]
+// [pixel row0 + 16 j + l15] of the BM x BN tile at (cm0, cn0).
+#pragma once
+#include "common.h"
+#include "igemm_args.h"
+#include "pp_sync.h"
+
+template <int FMW, int FNW, bool SLAB, int NT, int BM, int BN>
+__device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f32x4 (&acc)[FNW][FMW], int cm0, int cn0,
+                                              int row0, int col0, int l15, int kg, int t) {
+  if constexpr (SLAB) {
+    // ---- split-K: the fp32 tile goes to this split's slab (16 B per lane, 64-B runs per pixel row); bias / row
+    // vector / residual / GEGLU belong to splitk_reduce_kernel
+    float* dst = p.partial + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < FMW; ++j) {
+      const int m = cm0 + row0 + j * 16 + l15;
+#pragma unroll
+      for (int i = 0; i < FNW; ++i) {
+        const int n = cn0 + col0 + i * 16 + 4 * kg;
+        if (m < p.M && n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
+      }
+    }
+  } else {
+    // ---- fused epilogue: accumulators -> f16 tile in LDS ([BM][BN] halfs, rows padded by 16 B: the 16 lanes of a
+    // ds_write_b64 group fall in 16 different bank pairs) -> coalesced 16-byte-per-lane pass with bias / per-sample row
+    // vector / GELU / GEGLU / residual / scale in fp32
+    constexpr int RS = 2 * BN + 16;
+#pragma unroll
+    for (int j = 0; j < FMW; ++j) {
+      const int row = row0 + j * 16 + l15;
+#pragma unroll
+      for (int i = 0; i < FNW; ++i) {
+        const int col = col0 + i * 16 + 4 * kg;
+        union { f16 h[4]; uint2 u; } pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.h[e] = (f16)acc[i][j][e];
+        *(uint2*)(smem + row * RS + col * 2) = pk.u;
+      }
+    }
+    wait_lgkm0();
+    tick_barrier();
+    const float sc = p.out_scale;
+#ifdef RCDM_PP_EPI_U
+    constexpr int U = RCDM_PP_EPI_U;
+#else
+    constexpr int U = 8;  // staged reads / residual loads in flight per thread (measured: 8 is 1-2 % faster than 4 on the 64x64 convs)
+#endif
+    if (p.epi & RCDM_EPI_GEGLU) {
+      constexpr int CPR = BN / 16;  // output chunks (8 hidden columns) per row
+      constexpr int ITEMS = BM * CPR;
+      const int oc0 = geglu_out_col(cn0);
+      for (int base = 0; base < ITEMS; base += NT * U) {
+        Pack16 hh[U], gg[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = min(base + u * NT + t, ITEMS - 1);
+          const int row = idx / CPR, c = idx - row * CPR;
+          const int hc = (c >> 1) * 4 + (c & 1);
+          hh[u].u = *(const uint4*)(smem + row * RS + hc * 16);
+          gg[u].u = *(const uint4*)(smem + row * RS + (hc + 2) * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * NT + t;
+          const int row = idx / CPR, c = idx - row * CPR;
+          const int hc = (c >> 1) * 4 + (c & 1);
+          const int m = cm0 + row, pn = cn0 + hc * 8;
+          if (idx < ITEMS && m < p.M && pn < p.N) {
+            float bh[8], bg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bh[e] = bg[e] = 0.f;
+            if (p.epi & RCDM_EPI_BIAS) {
+              const f32x4 a0 = *(const f32x4*)(p.bias + pn), a1 = *(const f32x4*)(p.bias + pn + 4);
+              const f32x4 b0 = *(const f32x4*)(p.bias + pn + kGegluGroup), b1 = *(const f32x4*)(p.bias + pn + kGegluGroup + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                bh[e] = a0[e]; bh[4 + e] = a1[e];
+                bg[e] = b0[e]; bg[4 + e] = b1[e];
+              }
+            }
+            Pack16 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              o.e[e] = (f16)(((float)hh[u].e[e] + bh[e]) * gelu_f((float)gg[u].e[e] + bg[e]) * sc);
+            *(uint4*)(p.out + (size_t)m * p.ldc + oc0 + c * 8) = o.u;
+            if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + oc0 + c * 8 + p.dup) = o.u;
+          }
+        }
+      }
+    } else {
+      constexpr int CPR = BN / 8;
+      constexpr int ITEMS = BM * CPR;
+      const bool has_res = (p.epi & RCDM_EPI_RESIDUAL) != 0;
+      for (int base = 0; base < ITEMS; base += NT * U) {
+        Pack16 hh[U], rr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = min(base + u * NT + t, ITEMS - 1);
+          const int row = idx / CPR, c8 = idx - row * CPR;
+          const int m = cm0 + row, n = cn0 + c8 * 8;
+          hh[u].u = *(const uint4*)(smem + row * RS + c8 * 16);
+          rr[u].u = make_uint4(0, 0, 0, 0);
+          if (has_res && base + u * NT + t < ITEMS && m < p.M && n < p.N)
+            rr[u].u = *(const uint4*)(p.res + (size_t)m * p.ldr + n);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * NT + t;
+          const int row = idx / CPR, c8 = idx - row * CPR;
+          const int m = cm0 + row, n = cn0 + c8 * 8;
+          if (idx < ITEMS && m < p.M && n < p.N) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)hh[u].e[e];
+            if (p.epi & RCDM_EPI_BIAS) {
+              const f32x4 a0 = *(const f32x4*)(p.bias + n), a1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[e] += a0[e];
+                v[4 + e] += a1[e];
+              }
+            }
+            if (p.epi & RCDM_EPI_ROWVEC) {
+              const float* rv = p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + n;
+              const f32x4 a0 = *(const f32x4*)rv, a1 = *(const f32x4*)(rv + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[e] += a0[e];
+                v[4 + e] += a1[e];
+              }
+            }
+            if (p.epi & RCDM_EPI_GELU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            }
+            Pack16 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + (float)rr[u].e[e]) * sc);
+            *(uint4*)(p.out + (size_t)m * p.ldc + n) = o.u;
+            if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + n + p.dup) = o.u;
+          }
+        }
+      }
+    }
+  }
+}

@@ -221,15 +221,15 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int c_out, int 
     dst[i] = ci < c_in ? (f16)w[((size_t)co * c_in + ci) * 9 + tap] : (f16)0.f;
   }
 }
-// packed row p: grp = p/64, j = p%64; source row = j<32 ? grp*32+j (hidden) : n_out/2 + grp*32 + (j-32) (gate)
+// packed row p: grp = p/32, j = p%32; source row = j<16 ? grp*16+j (hidden) : n_out/2 + grp*16 + (j-16) (gate)
 __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n_out, int K,
                                   f16* __restrict__ wd, float* __restrict__ bd) {
   const size_t total = (size_t)n_out * K;
   const int half = n_out / 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % K), prow = (int)(i / K);
-    const int grp = prow >> 6, j = prow & 63;
-    const int src = j < 32 ? grp * 32 + j : half + grp * 32 + (j - 32);
+    const int grp = prow >> 5, j = prow & 31;
+    const int src = j < 16 ? grp * 16 + j : half + grp * 16 + (j - 16);
     wd[i] = (f16)w[(size_t)src * K + k];
     if (k == 0 && bias && bd) bd[prow] = bias[src];
   }
@@ -360,7 +360,7 @@ int rcdm_pack_conv3x3(const float* w, int32_t c_out, int32_t c_in, int32_t cin_p
 int rcdm_pack_geglu_rows(const float* w, const float* bias, int32_t n_out, int32_t K, void* w_dst, float* bias_dst,
                          void* stream) {
   if (!w || !w_dst || n_out <= 0 || K <= 0) return RCDM_EINVAL;
-  if (n_out % 64) return RCDM_ESHAPE;
+  if (n_out % 32) return RCDM_ESHAPE;
   const size_t n = (size_t)n_out * K;
   hipLaunchKernelGGL(pack_geglu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, bias, n_out, K,
                      (f16*)w_dst, bias_dst);

@@ -61,7 +61,7 @@ def ws(nbytes):
     (260, 64, 64, 1 | 2 | 4, 1),     # row vector with fewer rows per sample (100) than a 128-row tile: in-place reads
     (400, 320, 128, 1 | 2 | 4, 1),
 ])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm(hiplib, M, N, K, epi, split, variant):
     from rcdms_amd import hip
     hip.set_igemm_variant(variant)
@@ -110,7 +110,7 @@ def test_gemm_transpose_detecting(hiplib):
     close(out, W.t(), rel=1e-3, abs_frac=1e-3)
 
 
-@pytest.mark.parametrize("variant", [6, 7, 8])
+@pytest.mark.parametrize("variant", [6, 7, 8, 9])
 @pytest.mark.parametrize("M,N,K,epi,split", [
     (700, 648, 1000, 1 | 4, 1),      # several tiles both ways, ragged M / N, K tail (15 k-steps + 40), bias + residual
     (1280, 640, 704, 1, 0),          # 11 k-steps (odd), heuristic split
@@ -154,7 +154,7 @@ def test_gemm_pingpong(hiplib, M, N, K, epi, split, variant):
     assert torch.isnan(out[:, N:].float()).all(), "wrote outside the N columns"
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6, 8])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 8, 9])
 @pytest.mark.parametrize("split", [1, 2])
 def test_gemm_dup_rows(hiplib, variant, split):
     """rcdm_gemm_desc.dup_rows: every output row is also stored dup_rows further down (shared CFG prefix)."""
@@ -198,7 +198,7 @@ def test_gemm_pingpong_bitwise_vs_128(hiplib, variant):
     close(outs[0], outs[3].float(), rel=2e-3, abs_frac=1e-3)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("split", [1, 2])
 def test_gemm_geglu(hiplib, split, variant):
     from rcdms_amd import hip
@@ -232,7 +232,7 @@ def test_gemm_geglu(hiplib, split, variant):
     (2, 1, 8, 8, 320, 320, 1, 0, 4),    # split-K
     (2, 5, 16, 16, 128, 320, 1, 0, 0),  # 2560 pixels: several 160-row tiles, 18 k-steps, heuristic split
 ])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split, variant):
     from rcdms_amd import hip
     hip.set_igemm_variant(variant)
