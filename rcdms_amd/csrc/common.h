@@ -33,26 +33,55 @@ static inline int rcdm_check_launch() {
 
 // v_rcp_f32 (1 ulp) instead of an IEEE division: `a / b` and __frcp_rn expand to ~12 VALU ops on gfx950
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. at fp32 round-off level and three orders of
-// magnitude below the f16 output rounding): 1 rcp + 1 exp + 7 fma instead of libm erff's ~40 VALU ops, which made
-// the GEGLU epilogue VALU-bound.
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float r = 1.0f - p * t * __expf(-ax * ax);
-  return copysignf(r, x);
-}
-// exact-form (erf) GELU, as diffusers GEGLU.gelu -> F.gelu(approximate="none")
-__device__ __forceinline__ float gelu_f(float x) {
+// exact-form (erf) GELU, as diffusers GEGLU.gelu -> F.gelu(approximate="none"): x * Phi(x) with erf by Abramowitz &
+// Stegun 7.1.26 (max |error| of the GELU 3.3e-7 absolute over [-12, 12]: fp32 round-off level, three orders of magnitude
+// below the f16 output rounding; libm erff's ~40 VALU ops made the GEGLU epilogue VALU-bound).  With z = |x| / sqrt(2),
+// t = 1 / (1 + p z), q = (1 - erf(z)) / 2 = poly(t) * exp(-z^2) / 2:   gelu(x) = max(x, 0) - |x| * q
+// (sqrt(2) and the 1/2 are folded into the constants).  Written on pairs: v_pk_fma_f32 / v_pk_mul_f32 do two fp32
+// lanes per instruction, so a pair costs 6 packed ops + 2 rcp + 2 exp + 2 max; the epilogues of the K = 320 GEMMs
+// (50 GELUs per thread against 250 MFMAs per wave) are VALU-bound, DESIGN.md section 4a.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float a) { return f32x2{a, a}; }
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
 #ifdef RCDM_LIBM_ERF
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  return f32x2{0.5f * x.x * (1.0f + erff(x.x * 0.70710678118654752f)), 0.5f * x.y * (1.0f + erff(x.y * 0.70710678118654752f))};
 #else
-  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f));
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  const f32x2 d = __builtin_elementwise_fma(ax, splat2(0.2316418882f), splat2(1.0f));  // 0.3275911 / sqrt(2)
+  const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  f32x2 p = __builtin_elementwise_fma(t, splat2(0.5307027145f), splat2(-0.7265760135f));  // A&S coefficients / 2
+  p = __builtin_elementwise_fma(p, t, splat2(0.7107068705f));
+  p = __builtin_elementwise_fma(p, t, splat2(-0.142248368f));
+  p = __builtin_elementwise_fma(p, t, splat2(0.127414796f));
+  const f32x2 xx = x * x * splat2(-0.72134752044f);  // -z^2 * log2(e)
+  const f32x2 e = {__builtin_amdgcn_exp2f(xx.x), __builtin_amdgcn_exp2f(xx.y)};
+  const f32x2 q = p * t * e;
+  return __builtin_elementwise_fma(-ax, q, __builtin_elementwise_max(x, splat2(0.0f)));
 #endif
+}
+__device__ __forceinline__ float gelu_f(float x) { return gelu2(splat2(x)).x; }
+__device__ __forceinline__ void gelu8(float (&v)[8]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2 r = gelu2(f32x2{v[2 * k], v[2 * k + 1]});
+    v[2 * k] = r.x;
+    v[2 * k + 1] = r.y;
+  }
+}
+// GEGLU on eight packed halfs: (h + bh) * gelu(g + bg) * sc -> eight halfs
+__device__ __forceinline__ uint4 geglu8(uint4 h, uint4 g, const float (&bh)[8], const float (&bg)[8], float sc) {
+  union P { uint4 u; f16 e[8]; } hh, gg, o;
+  hh.u = h;
+  gg.u = g;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2 hv = f32x2{(float)hh.e[2 * k], (float)hh.e[2 * k + 1]} + f32x2{bh[2 * k], bh[2 * k + 1]};
+    const f32x2 gv = f32x2{(float)gg.e[2 * k], (float)gg.e[2 * k + 1]} + f32x2{bg[2 * k], bg[2 * k + 1]};
+    const f32x2 r = hv * gelu2(gv) * splat2(sc);
+    o.e[2 * k] = (f16)r.x;
+    o.e[2 * k + 1] = (f16)r.y;
+  }
+  return o.u;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -52,8 +52,9 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n,
         g[e] += bg[e];
       }
     }
+    gelu8(g);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= gelu_f(g[e]);
+    for (int e = 0; e < 8; ++e) v[e] *= g[e];
     oc = geglu_out_col(n);
   } else if (p.epi & RCDM_EPI_BIAS) {
     float bb[8];
@@ -67,10 +68,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n,
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += rv[e];
   }
-  if (p.epi & RCDM_EPI_GELU) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-  }
+  if (p.epi & RCDM_EPI_GELU) gelu8(v);
   if (p.epi & RCDM_EPI_RESIDUAL) {
     Pack16 r;
     r.u = *(const uint4*)(p.res + (size_t)m * p.ldr + oc);
@@ -451,12 +449,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
                 const int m = mbase + gr0 + (it0 + k) * G_RPI;
                 if (m < p.M && pn_ok) {
                   Pack16 o;
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) {
-                    const float hv = mix_f16_f32(hh[k].v[e >> 1], e & 1, 1.0f, bA[e]);
-                    const float gv = mix_f16_f32(gg[k].v[e >> 1], e & 1, 1.0f, bB[e]);
-                    o.e[e] = (f16)(hv * gelu_f(gv) * sc);
-                  }
+                  o.u = geglu8(hh[k].u, gg[k].u, bA, bB, sc);
                   *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
                   if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + oc + p.dup) = o.u;
                 }
@@ -500,8 +493,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
                       for (int e = 0; e < 8; ++e) v[e] += rv[e];
                     }
                     if (gelu_on) {
-#pragma unroll
-                      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                      gelu8(v);
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + (float)rr.e[e]) * sc);
