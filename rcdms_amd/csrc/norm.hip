@@ -10,12 +10,14 @@
 
 namespace {
 
+constexpr int GN_U = 8;  // 16-byte loads a thread of the stats / apply kernels keeps in flight
+
 struct GnArgs {
   const f16* x;
   f16* y;
   const float* gamma;
   const float* beta;
-  float* partial;  // [samples][splits][groups][3] = (count, mean, M2)
+  float* partial;  // [samples][groups][splits][3] = (count, mean, M2)
   float* stat;     // [samples][groups][2] = (mean, rstd)
   int samples, P, C, G, cg, CH, RPB, ldx, ldy, splits, rows_per_split;
   float eps;
@@ -35,17 +37,18 @@ __global__ void gn_stats_kernel(const GnArgs p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
   const f16* base = p.x + (size_t)s * p.P * p.ldx + ch * 8;
-  // four independent 16-byte loads in flight per thread; rows past r_end read as zero and add nothing
-  for (int r = r_begin + rl; r < r_end; r += 4 * p.RPB) {
-    Pack16 v[4];
+  // GN_U independent 16-byte loads in flight per thread (the split is sized so that this is normally the block's ONE
+  // memory round trip: a launch this short is a chain of latencies, not a stream); rows past r_end add nothing
+  for (int r = r_begin + rl; r < r_end; r += GN_U * p.RPB) {
+    Pack16 v[GN_U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GN_U; ++u) {
       const int ru = r + u * p.RPB;
       v[u].u = make_uint4(0, 0, 0, 0);
       if (ru < r_end) v[u].u = *(const uint4*)(base + (size_t)ru * p.ldx);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < GN_U; ++u)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float f = (float)v[u].e[e];
@@ -59,19 +62,31 @@ __global__ void gn_stats_kernel(const GnArgs p) {
     part[t * 16 + 8 + e] = sq[e];
   }
   __syncthreads();
+  // column sums first (CH * 16 values, each over the RPB row-threads, spread over the whole block), then the G groups:
+  // the one-step form (G threads walking RPB * cg entries each) was a 120-read serial tail on 32 threads per block
+  const float* colsum = part;  // one row-thread per chunk: the per-thread sums ARE the column sums
+  if (p.RPB > 1) {
+    float* cs = part + blockDim.x * 16;
+    for (int o = t; o < p.CH * 16; o += blockDim.x) {
+      const int c = o >> 4, k = o & 15;
+      float a = 0.f;
+      for (int r = 0; r < p.RPB; ++r) a += part[(r * p.CH + c) * 16 + k];
+      cs[o] = a;
+    }
+    colsum = cs;
+    __syncthreads();
+  }
   if (t < p.G) {
     float gs = 0.f, gq = 0.f;
-    for (int r = 0; r < p.RPB; ++r)
-      for (int c = t * p.cg; c < (t + 1) * p.cg; ++c) {
-        const int src = (r * p.CH + (c >> 3)) * 16 + (c & 7);
-        gs += part[src];
-        gq += part[src + 8];
-      }
+    for (int c = t * p.cg; c < (t + 1) * p.cg; ++c) {
+      gs += colsum[(c >> 3) * 16 + (c & 7)];
+      gq += colsum[(c >> 3) * 16 + 8 + (c & 7)];
+    }
     const float n = (float)(r_end - r_begin) * (float)p.cg;
     const float mean = n > 0.f ? gs / n : 0.f;
     float m2 = gq - gs * mean;
     if (m2 < 0.f) m2 = 0.f;
-    float* o = p.partial + (((size_t)s * p.splits + sp) * p.G + t) * 3;
+    float* o = p.partial + (((size_t)s * p.G + t) * p.splits + sp) * 3;
     o[0] = n;
     o[1] = mean;
     o[2] = m2;
@@ -97,9 +112,23 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs p) {
   if (idx >= p.samples * p.G) return;
   const int s = idx / p.G, g = idx - s * p.G;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int sp = lane; sp < p.splits; sp += 64) {
-    const float* o = p.partial + (((size_t)s * p.splits + sp) * p.G + g) * 3;
-    chan_combine(n, mean, m2, o[0], o[1], o[2]);
+  // the (sample, group)'s partials are contiguous: all of a lane's (<= 8) are requested before the first combine, one
+  // round trip instead of splits / 64 dependent ones
+  const float* base = p.partial + (size_t)idx * p.splits * 3;
+  for (int sp0 = 0; sp0 < p.splits; sp0 += 512) {
+    float pn[8], pm[8], pq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int sp = sp0 + lane + 64 * i;
+      pn[i] = pm[i] = pq[i] = 0.f;
+      if (sp < p.splits) {
+        pn[i] = base[sp * 3];
+        pm[i] = base[sp * 3 + 1];
+        pq[i] = base[sp * 3 + 2];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) chan_combine(n, mean, m2, pn[i], pm[i], pq[i]);
   }
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -141,7 +170,7 @@ __global__ void gn_apply_kernel(const GnArgs p) {
   for (int r = blockIdx.x * p.RPB + rl; r < p.P; r += 4 * rstep) {
     Pack16 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)  // four loads in flight
+    for (int u = 0; u < 4; ++u)  // four loads in flight (eight measured 5-10 % slower here)
       if (r + u * rstep < p.P) v[u].u = *(const uint4*)(xb + (size_t)(r + u * rstep) * p.ldx);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -284,10 +313,14 @@ int gn_plan(const rcdm_groupnorm_desc* d, GnArgs& a) {
   if (a.RPB < 1) a.RPB = 1;
   if (a.CH * a.RPB < a.G) a.RPB = (a.G + a.CH - 1) / a.CH;  // need >= G threads for the group pass
   a.ldx = d->ldx; a.ldy = d->ldy; a.eps = d->eps; a.silu = d->silu;
-  int splits = (768 + a.samples - 1) / a.samples;
-  const int max_splits = (a.P + 4 * a.RPB - 1) / (4 * a.RPB);  // >= 4 row passes per block
-  if (splits > max_splits) splits = max_splits;
-  if (splits > 256) splits = 256;
+  // one pass of GN_U rows per thread where that gives a chip-filling grid (<= 1024 blocks per launch), else several
+  int splits = (a.P + GN_U * a.RPB - 1) / (GN_U * a.RPB);
+  const int fill = (768 + a.samples - 1) / a.samples;              // small tensors: still >= 768 blocks per launch ...
+  const int max_splits = (a.P + 2 * a.RPB - 1) / (2 * a.RPB);      // ... while every thread keeps >= 2 rows
+  if (splits < fill) splits = fill < max_splits ? fill : max_splits;
+  const int cap = (1024 + a.samples - 1) / a.samples;
+  if (splits > cap) splits = cap;
+  if (splits > 512) splits = 512;
   if (splits < 1) splits = 1;
   a.rows_per_split = (a.P + splits - 1) / splits;
   a.splits = (a.P + a.rows_per_split - 1) / a.rows_per_split;
@@ -387,6 +420,124 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
   }
 }
 
+// LayerNorm, row-group form (the one rcdm_layernorm launches): LPR lanes share a row (a power of two, 8..64), each lane
+// owns CPL 16-byte chunks c = k * LPR + l, so a wave normalises 64 / LPR rows at once with EVERY lane loading (the
+// wave-per-row form above has 40 of 64 lanes busy at C = 320) and each load instruction covering whole 128-byte lines.
+// The two row reductions (mean, then sum of squared deviations: exact two-pass, in registers) are log2(LPR) DPP steps
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: no LDS crossbar) instead of six ds_bpermute round trips: the
+// wave-per-row kernel spent its life in those dependent shuffles (3.65 TB/s where a plain copy of the same bytes runs at
+// 6.2 TB/s on this part).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);  // row_half_mirror: quads are uniform by now, so the mirrored partner is the other quad's sum
+  if constexpr (LPR >= 16) v += dpp_f32<0x140>(v);  // row_mirror: the other 8-lane group of the 16-lane row
+  if constexpr (LPR >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (LPR >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int LPR, int CPL, bool EARLY>
+__global__ __launch_bounds__(256) void layernorm_grp_kernel(const f16* __restrict__ x, f16* __restrict__ y,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ pe, int M, int C, int ldx,
+                                                            int ldy, float eps, int rows_per_frame, int frames) {
+  constexpr int RW = 64 / LPR;  // rows per wave
+  const int lane = threadIdx.x & 63, l = lane & (LPR - 1), rw = lane / LPR;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW + rw;
+  const bool live = row < M;
+  const int nchunks = C >> 3;
+  Pack16 raw[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int c = k * LPR + l;
+    raw[k].u = make_uint4(0, 0, 0, 0);
+    if (live && c < nchunks) raw[k].u = *(const uint4*)(x + (size_t)row * ldx + c * 8);
+  }
+  // EARLY (launches of <= 3 waves per SIMD, where registers are free): the affine parameters and the positional-encoding
+  // row are requested right behind the data, one memory round trip instead of two on the critical path of a launch that
+  // is a single shot of latency anyway
+  f32x4 eg0[EARLY ? CPL : 1], eg1[EARLY ? CPL : 1], eb0[EARLY ? CPL : 1], eb1[EARLY ? CPL : 1];
+  if constexpr (EARLY) {
+    const float* pe_row = pe ? pe + (size_t)(((live ? row : 0) / rows_per_frame) % frames) * C : nullptr;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = min(k * LPR + l, nchunks - 1);
+      eg0[k] = *(const f32x4*)(gamma + c * 8);
+      eg1[k] = *(const f32x4*)(gamma + c * 8 + 4);
+      eb0[k] = *(const f32x4*)(beta + c * 8);
+      eb1[k] = *(const f32x4*)(beta + c * 8 + 4);
+      if (pe_row) {
+        eb0[k] += *(const f32x4*)(pe_row + c * 8);
+        eb1[k] += *(const f32x4*)(pe_row + c * 8 + 4);
+      }
+    }
+  }
+  // fp32 pairs: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 do two lanes' worth per instruction (the kernel's ~400 scalar
+  // VALU ops per wave were 3 us of the whole chip's issue capacity per 26-MB tensor)
+  f32x2 v[CPL][4];
+  f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < CPL; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[k][e] = f32x2{(float)raw[k].e[2 * e], (float)raw[k].e[2 * e + 1]};
+      s2 += v[k][e];
+    }
+  const float invC = 1.0f / (float)C;
+  const float mean = group_sum<LPR>(s2.x + s2.y) * invC;
+  f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < CPL; ++k)
+    if (k * LPR + l < nchunks) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[k][e] -= splat2(mean);
+        q2 = __builtin_elementwise_fma(v[k][e], v[k][e], q2);
+      }
+    }
+  const float rstd = rsqrtf(group_sum<LPR>(q2.x + q2.y) * invC + eps);
+  if (!live) return;
+  // affine parameters are fetched here, late, on purpose: held across the reductions they cost 56 VGPRs, i.e. three waves
+  // per SIMD instead of six, and the 5120 waves of a 64x64-level tensor then need two rounds instead of one (measured:
+  // 12.3 vs 10.9 us); they are L1/L2 hits
+  const float* pe_row = pe ? pe + (size_t)((row / rows_per_frame) % frames) * C : nullptr;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int c = k * LPR + l;
+    if (c < nchunks) {
+      f32x4 g0, g1, b0, b1;
+      if constexpr (EARLY) {
+        g0 = eg0[k]; g1 = eg1[k]; b0 = eb0[k]; b1 = eb1[k];
+      } else {
+        g0 = *(const f32x4*)(gamma + c * 8);
+        g1 = *(const f32x4*)(gamma + c * 8 + 4);
+        b0 = *(const f32x4*)(beta + c * 8);
+        b1 = *(const f32x4*)(beta + c * 8 + 4);
+        if (pe_row) {
+          b0 += *(const f32x4*)(pe_row + c * 8);
+          b1 += *(const f32x4*)(pe_row + c * 8 + 4);
+        }
+      }
+      const f32x2 r2 = splat2(rstd);
+      const f32x2 o0 = __builtin_elementwise_fma(v[k][0] * r2, f32x2{g0[0], g0[1]}, f32x2{b0[0], b0[1]});
+      const f32x2 o1 = __builtin_elementwise_fma(v[k][1] * r2, f32x2{g0[2], g0[3]}, f32x2{b0[2], b0[3]});
+      const f32x2 o2 = __builtin_elementwise_fma(v[k][2] * r2, f32x2{g1[0], g1[1]}, f32x2{b1[0], b1[1]});
+      const f32x2 o3 = __builtin_elementwise_fma(v[k][3] * r2, f32x2{g1[2], g1[3]}, f32x2{b1[2], b1[3]});
+      Pack16 o;
+      o.e[0] = (f16)o0.x; o.e[1] = (f16)o0.y; o.e[2] = (f16)o1.x; o.e[3] = (f16)o1.y;
+      o.e[4] = (f16)o2.x; o.e[5] = (f16)o2.y; o.e[6] = (f16)o3.x; o.e[7] = (f16)o3.y;
+      *(uint4*)(y + (size_t)row * ldy + c * 8) = o.u;
+    }
+  }
+}
+
 // Row softmax over f16 rows (fp32 math): y[m][n] = softmax_n(scale * x[m][n]).  One wave per row, the row held in
 // registers across the max / sum passes.  Used where a head dim is too wide for the flash kernel (the VAE mid-block
 // attention: one head of 512 channels over 64 x 64 tokens), where scores are materialised by two GEMMs instead.
@@ -478,7 +629,15 @@ int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float
   hipStream_t stream = (hipStream_t)stream_;
   const int threads = a.CH * a.RPB;
   if (threads > 1024) return RCDM_ESHAPE;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.splits, a.samples), dim3(threads), threads * 16 * sizeof(float), stream, a);
+  const size_t stats_lds = (size_t)(threads + a.CH) * 16 * sizeof(float);
+  if (stats_lds > 64 * 1024) {  // C > 4096: beyond the default dynamic-LDS limit
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gn_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.splits, a.samples), dim3(threads), stats_lds, stream, a);
   rc = rcdm_check_launch();
   if (rc) return rc;
   const int nsg = a.samples * a.G;
@@ -500,9 +659,46 @@ int rcdm_layernorm(const rcdm_layernorm_desc* d, const void* x, const float* gam
   if ((d->C & 7) || d->C > 2048 || (d->ldx & 7) || (d->ldy & 7)) return RCDM_ESHAPE;
   if (pe && (d->rows_per_frame <= 0 || d->frames <= 0)) return RCDM_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
-  const int nch = ((d->C >> 3) + 63) / 64;
+  const int nchunks = d->C >> 3;
   dim3 block(256);
   const int rpf = pe ? d->rows_per_frame : 1, fr = pe ? d->frames : 1;
+  static int wave_rows = -1;  // RCDM_LN_WAVEROW=1: the round-1 wave-per-row kernel (A/B switch)
+  if (wave_rows < 0) {
+    const char* e = getenv("RCDM_LN_WAVEROW");
+    wave_rows = e ? atoi(e) : 0;
+  }
+  if (!wave_rows) {
+    const int lpr = nchunks <= 40 ? 8 : nchunks <= 80 ? 16 : nchunks <= 160 ? 32 : 64;
+    const int cpl = (nchunks + lpr - 1) / lpr;
+    const int rows_per_block = 4 * (64 / lpr);
+    const int nblocks = (d->M + rows_per_block - 1) / rows_per_block;
+    const bool early = nblocks <= 3 * 256;  // <= 3 waves per SIMD: registers are free, latency is everything
+#define LNG_LAUNCH(L, K)                                                                                              \
+  if (early)                                                                                                          \
+    hipLaunchKernelGGL((layernorm_grp_kernel<L, K, true>), dim3(nblocks), block, 0, stream, (const f16*)x, (f16*)y,   \
+                       gamma, beta, pe, d->M, d->C, d->ldx, d->ldy, d->eps, rpf, fr);                                 \
+  else                                                                                                                \
+    hipLaunchKernelGGL((layernorm_grp_kernel<L, K, false>), dim3(nblocks), block, 0, stream, (const f16*)x, (f16*)y,  \
+                       gamma, beta, pe, d->M, d->C, d->ldx, d->ldy, d->eps, rpf, fr)
+#define LNG_CPL(L)                  \
+  switch (cpl) {                    \
+    case 1: LNG_LAUNCH(L, 1); break; \
+    case 2: LNG_LAUNCH(L, 2); break; \
+    case 3: LNG_LAUNCH(L, 3); break; \
+    case 4: LNG_LAUNCH(L, 4); break; \
+    default: LNG_LAUNCH(L, 5); break; \
+  }
+    switch (lpr) {
+      case 8: LNG_CPL(8); break;
+      case 16: LNG_CPL(16); break;
+      case 32: LNG_CPL(32); break;
+      default: LNG_CPL(64); break;
+    }
+#undef LNG_CPL
+#undef LNG_LAUNCH
+    return rcdm_check_launch();
+  }
+  const int nch = (nchunks + 63) / 64;
 #define LN_LAUNCH(N, R)                                                                                      \
   hipLaunchKernelGGL((layernorm_kernel<N, R>), dim3((d->M + 4 * R - 1) / (4 * R)), block, 0, stream,        \
                      (const f16*)x, (f16*)y, gamma, beta, pe, d->M, d->C, d->ldx, d->ldy, d->eps, rpf, fr)

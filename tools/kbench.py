@@ -150,8 +150,18 @@ def bench_attn(rounds, only=""):
         print(f"attn {name:28s} {by / 1e6:8.1f} MB | {med:7.1f}us {by / med / 1e6:6.2f}TB/s", flush=True)
 
 
-def bench_norm(rounds):
+def bench_norm(rounds, only=""):
+    for name, M, C in [("copy 26 MB (torch)", 40960, 320), ("copy 13 MB (torch)", 10240, 640), ("copy 6.5 MB (torch)", 2560, 1280),
+                       ("copy 79 MB (torch)", 40960, 960)]:
+        if only and only not in name:
+            continue
+        x = torch.randn(M, C, device=DEV).half()
+        y = torch.empty_like(x)
+        med, mn = timeit(lambda: y.copy_(x), rounds)  # bandwidth yardstick for the norm kernels below (same bytes)
+        print(f"norm {name:28s} {4.0 * M * C / 1e6:8.1f} MB | {med:7.1f}us {4.0 * M * C / med / 1e6:6.2f}TB/s", flush=True)
     for name, M, C in [("L0 LN C=320", 40960, 320), ("L1 LN C=640", 10240, 640), ("L2 LN C=1280", 2560, 1280)]:
+        if only and only not in name:
+            continue
         x = torch.randn(M, C, device=DEV).half()
         y = torch.empty_like(x)
         g, b = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
@@ -159,7 +169,10 @@ def bench_norm(rounds):
         med, mn = timeit(lambda: hip.layernorm(d, x.data_ptr(), g.data_ptr(), b.data_ptr(), 0, y.data_ptr()), rounds)
         print(f"norm {name:28s} {4.0 * M * C / 1e6:8.1f} MB | {med:7.1f}us {4.0 * M * C / med / 1e6:6.2f}TB/s", flush=True)
     for name, smp, rps, C, silu in [("L0 GN cross C=320", 2, 20480, 320, 1), ("L0 GN cross C=960", 2, 20480, 960, 1),
-                                    ("L0 GN frame C=320", 10, 4096, 320, 0), ("L2 GN cross C=1280", 2, 1280, 1280, 1)]:
+                                    ("L0 GN frame C=320", 10, 4096, 320, 0), ("L2 GN cross C=1280", 2, 1280, 1280, 1),
+                                    ("L1 GN cross C=640", 2, 5120, 640, 1), ("L1 GN frame C=640", 10, 1024, 640, 0)]:
+        if only and only not in name:
+            continue
         x = torch.randn(smp * rps, C, device=DEV).half()
         y = torch.empty_like(x)
         g, b = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
@@ -189,4 +202,4 @@ if __name__ == "__main__":
     if a.what in ("attn", "all"):
         bench_attn(a.rounds, a.only)
     if a.what in ("norm", "all"):
-        bench_norm(a.rounds)
+        bench_norm(a.rounds, a.only)
