@@ -114,6 +114,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-share-prefix", action="store_true",
                     help="evaluate the part of the UNet ahead of the first cross-attention for BOTH CFG halves (A/B switch; "
                          "the default evaluates it once: the halves' inputs are identical there and the result is exact)")
+    ap.add_argument("--cfg-split", action="store_true",
+                    help="latency mode (not the headline metric): two GPUs per story, one CFG half each, noise predictions "
+                         "all-gathered over RCCL inside the step graph; with --gpus 1 ONE half is timed against a one-rank "
+                         "communicator (what a rank of a pair does per step, the exchange being a local copy)")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="TEST ONLY: exercise the launch / barrier / max-over-ranks harness on CPU (gloo) with a sleep "
                          "in place of the denoising loop; the printed line is marked data=stub and is not a measurement")
@@ -178,7 +182,7 @@ def traffic_record(S, latent, guidance):
             rec = json.load(f)
         from rcdms_amd import build as rbuild
         src = f"profiles/hbm_traffic.json@{rec.get('commit', 'unknown')}"
-        if rec.get("csrc_stamp") and rec["csrc_stamp"] != rbuild._stamp():
+        if rec.get("csrc_stamp") != rbuild._stamp():   # an unstamped record counts as stale too
             return None, src + " (stale: kernels changed since; not reported)"
         return float(rec["hbm_bytes_per_unet_step"]), src
     except Exception:
@@ -243,8 +247,17 @@ def main(argv=None):
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
     S, T = a.stories, a.ddim_steps
     story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42 + rank)
+    split, units = None, world          # units = independent story batches in flight across the job
+    if a.cfg_split:
+        from rcdms_amd.dist import CfgSplit
+        if world == 1:
+            comm = hip.Comm(hip.Comm.unique_id(), 1, 0)
+            split = CfgSplit(0, lambda send, recv, n: comm.allgather(send, recv, n))
+        else:
+            split, units = CfgSplit.from_world(), world // 2
+            story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42 + rank // 2)
     loop = DenoiseLoop(model, S, 5, a.latent, a.latent, a.ctx_len, a.guidance, sched, T,
-                       share_cfg_prefix=not a.no_share_prefix)
+                       share_cfg_prefix=not a.no_share_prefix, cfg_split=split)
 
     def one_pass():
         loop.load(story["latents"], story["mask"], story["masked_latents"], story["ctx"])
@@ -268,16 +281,16 @@ def main(argv=None):
 
     dt, per_rank = timed_passes(timed_pass, a.steps, dist if dist_on else None, torch.cuda.synchronize, dev)
 
-    frames = 5 * S * a.steps * world
+    frames = 5 * S * a.steps * units
     value = frames / dt
     launches = a.steps * T
     avg_launch_ms = gpu_ms[0] / launches
     tf_call = ALGO_TFLOP_PER_CALL.get(a.latent)
-    traffic, traffic_src = traffic_record(S, a.latent, a.guidance)
+    traffic, traffic_src = traffic_record(S, a.latent, a.guidance) if not a.cfg_split else (None, None)
     roof = None
     if tf_call is not None:
-        achieved = tf_call * S / (avg_launch_ms * 1e-3)
-        roof = {"bound": "mfma", "kernel": "denoise-step graph (UNet b=%d + CFG + DDIM)" % (2 * S if a.guidance > 1 else S),
+        achieved = tf_call * S / (avg_launch_ms * 1e-3) * (0.5 if a.cfg_split else 1.0)   # a split rank evaluates one CFG half
+        roof = {"bound": "mfma", "kernel": "denoise-step graph (UNet b=%d + CFG + DDIM)" % (2 * S if a.guidance > 1 and not a.cfg_split else S),
                 "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches}
@@ -290,7 +303,9 @@ def main(argv=None):
         "config": {"workload": f"{'FlintstonesSV' if a.ctx_len == 91 else 'PororoSV'} stage-2, {a.latent * 8}x{a.latent * 8}, "
                                f"{T}-step DDIM, CFG {a.guidance}, "
                                f"batch={S} story x 5 frames per GPU, ctx {a.ctx_len}x768, random-init 1276.9M-param UNet3D",
-                   "stories_per_gpu": S, "latent": a.latent, "ddim_steps": T, "parallelism": f"story-replicas x{world}",
+                   "stories_per_gpu": S, "latent": a.latent, "ddim_steps": T, "parallelism": (f"story-replicas x{world}" if not a.cfg_split else
+                                   "cfg-split: one CFG half timed, one-rank all-gather" if world == 1 else
+                                   f"cfg-split pairs x{world // 2} (2 GPUs per story, RCCL all-gather per step)"),
                    "shared_cfg_prefix": bool(loop.shared)},
         "per_rank_ms": [round(1e3 * x / a.steps, 3) for x in per_rank],
         "roofline": roof,

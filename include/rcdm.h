@@ -33,6 +33,7 @@ extern "C" {
 #define RCDM_ESHAPE (-2)   /* shape not supported by this kernel */
 #define RCDM_ELAUNCH (-3)  /* HIP launch / runtime error (see rcdm_last_hip_error) */
 #define RCDM_EWORKSPACE (-4) /* workspace too small */
+#define RCDM_ECOMM (-5)    /* RCCL missing or an RCCL call failed (see rcdm_comm_last_error) */
 
 /* epilogue flags for rcdm_gemm / rcdm_conv3x3 (applied in fp32, one final rounding to f16) */
 #define RCDM_EPI_BIAS 1      /* + bias[n]                              (fp32 [N])                  */
@@ -294,6 +295,25 @@ int rcdm_event_record(void* ev, void* stream);
 int rcdm_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on stop */
 int rcdm_event_destroy(void* ev);
 int rcdm_stream_synchronize(void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Thin RCCL layer (librccl is dlopen'ed on first use; a single-GPU process never maps it).  The reference has no
+ * inter-GPU communication at all: stage2_batchtest_rcdms_model.py:457-468 spawns one process per device and every
+ * process loads every checkpoint.  These serve the packed-weight broadcast and the CFG-split latency mode (two GPUs
+ * per story, one classifier-free-guidance half each, RCDMs_pipeline.py:482-497: the halves' noise predictions are
+ * all-gathered inside the step graph).  Byte-typed, in place on the caller's HIP stream, graph-capturable.
+ *   rcdm_comm_unique_id: rank 0 of a group fills 128 bytes, the caller ships them to the other ranks out of band
+ *                        (file, socket, torch.distributed object broadcast);
+ *   rcdm_comm_create:    collective over the group's ranks (blocks until all have called it);
+ *   rcdm_bcast:          `bytes` at `buf` from rank `root` to every rank's `buf`;
+ *   rcdm_allgather:      recv[r * bytes_per_rank ...] on every rank = rank r's send (send may alias its own slot).
+ * ---------------------------------------------------------------------------------------------- */
+int rcdm_comm_unique_id(void* id128);
+int rcdm_comm_create(const void* id128, int32_t nranks, int32_t rank, void** comm_out);
+int rcdm_comm_destroy(void* comm);
+int rcdm_bcast(void* comm, void* buf, size_t bytes, int32_t root, void* stream);
+int rcdm_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int rcdm_comm_last_error(void); /* last non-zero ncclResult_t seen on this thread */
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,9 @@ independent unit is the story.  What RCCL is used for here:
   * broadcast_module: rank 0 loads / initialises the weights once, every other rank receives them over xGMI
     (2.55 GB as f16, 5.1 GB as the fp32 state dict; bucketed so each collective is a few hundred MB);
   * broadcast_context / gather_stories: shared reference context out, finished latents back to rank 0.
-The denoising loop itself contains no collective ("weak" scaling by construction).
+The denoising loop itself contains no collective ("weak" scaling by construction) — except in the optional CFG-split
+latency mode (cfg_split_layout / CfgSplit below): two GPUs per story, each evaluates one classifier-free-guidance half
+of the UNet and the two 164-KB noise predictions are all-gathered inside the step graph.
 Works with backend "nccl" (= RCCL on ROCm) and "gloo" (CPU tests)."""
 import torch
 import torch.distributed as dist
@@ -83,3 +85,59 @@ def gather_stories(latents, dst=0):
     if rank != dst:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CFG-split latency mode.  Reference arithmetic: RCDMs_pipeline.py:482-497 — latent_model_input = cat([latents] * 2),
+# noise_pred_uncond, noise_pred_text = noise_pred.chunk(2); batch elements never interact inside the UNet, so the two
+# halves can run on two devices and only the noise predictions meet.
+
+def cfg_split_layout(world_size, rank):
+    """(pair index, half, partner rank) of `rank` when ranks are paired (0,1), (2,3), ...: the even rank of a pair
+    evaluates the unconditional half (batch rows [0, S)), the odd rank the conditional half ([S, 2S)) — the order of
+    the reference's CFG batch.  Story shards are dealt to PAIRS: split_stories(n, world_size // 2)[pair]."""
+    if world_size < 2 or world_size % 2:
+        raise ValueError(f"CFG split pairs the ranks: world size {world_size} is not a positive even number")
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    return rank // 2, rank % 2, rank ^ 1
+
+
+def exchange_unique_id(make_id, world_size, rank):
+    """Every pair's even rank draws an id with make_id() (rcdms_amd.hip.Comm.unique_id); returns the id of this
+    rank's pair on both of its members.  One all_gather_object over the default group (any backend)."""
+    mine = make_id() if rank % 2 == 0 else None
+    ids = [None] * world_size
+    dist.all_gather_object(ids, mine)
+    return ids[rank - (rank % 2)]
+
+
+class CfgSplit:
+    """What DenoiseLoop needs to run one CFG half: which half, and `allgather(send_ptr, recv_ptr, nbytes)` enqueueing
+    the exchange of the two halves' noise predictions on the current stream (recv holds [uncond | cond])."""
+
+    def __init__(self, half, allgather):
+        self.half = int(half)
+        self.allgather = allgather
+
+    @classmethod
+    def from_world(cls):
+        """Pair communicators over RCCL through the C-ABI (rcdm_comm_*), ids exchanged through torch.distributed."""
+        from . import hip
+        world, rank = dist.get_world_size(), dist.get_rank()
+        _, half, _ = cfg_split_layout(world, rank)
+        uid = exchange_unique_id(hip.Comm.unique_id, world, rank)
+        comm = hip.Comm(uid, 2, half)
+        obj = cls(half, comm.allgather)
+        obj.comm = comm
+        return obj
+
+
+def cfg_split_reference_step(eps_fn, x, ctx_u, ctx_c, half, allgather_tensors):
+    """Host restatement of one split step's data flow (CPU tests over gloo): this rank evaluates eps_fn on ITS half
+    only, the halves are all-gathered, and the caller applies CFG + DDIM to the gathered pair exactly as the unsplit
+    loop does.  Returns (eps_uncond, eps_cond)."""
+    mine = eps_fn(x, ctx_u if half == 0 else ctx_c).contiguous()
+    both = [torch.empty_like(mine), torch.empty_like(mine)]
+    allgather_tensors(both, mine)
+    return both[0], both[1]

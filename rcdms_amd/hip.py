@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("RCDM_LIB") or os.path.join(_HERE, "lib", "librcdm_hip
 
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU, EPI_GELU = 1, 2, 4, 8, 16
 
-_ERR = {-1: "RCDM_EINVAL", -2: "RCDM_ESHAPE", -3: "RCDM_ELAUNCH", -4: "RCDM_EWORKSPACE"}
+_ERR = {-1: "RCDM_EINVAL", -2: "RCDM_ESHAPE", -3: "RCDM_ELAUNCH", -4: "RCDM_EWORKSPACE", -5: "RCDM_ECOMM"}
 
 
 class RcdmError(RuntimeError):
@@ -101,6 +101,12 @@ SYMBOLS = {
     "rcdm_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "rcdm_event_destroy": (C.c_int, [_P]),
     "rcdm_stream_synchronize": (C.c_int, [_P]),
+    "rcdm_comm_unique_id": (C.c_int, [_P]),
+    "rcdm_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "rcdm_comm_destroy": (C.c_int, [_P]),
+    "rcdm_bcast": (C.c_int, [_P, _P, C.c_size_t, C.c_int32, _P]),
+    "rcdm_allgather": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    "rcdm_comm_last_error": (C.c_int, []),
 }
 
 _lib = None
@@ -130,6 +136,8 @@ def _check(rc, what):
         extra = ""
         if rc == -3:
             extra = f" (hip error {lib.rcdm_last_hip_error()}: {lib.rcdm_last_hip_error_string().decode()})"
+        if rc == -5:
+            extra = f" (ncclResult {lib.rcdm_comm_last_error()}; 0 = librccl could not be opened)"
         raise RcdmError(f"{what} failed: {_ERR.get(rc, rc)}{extra}")
 
 
@@ -292,6 +300,45 @@ class Graph:
         try:
             if self.exec and _lib is not None:
                 _lib.rcdm_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+class Comm:
+    """An RCCL communicator behind the C-ABI (rcdm_comm_*): broadcast / all-gather of raw device bytes on the current
+    (or a given) HIP stream.  `unique_id()` on one rank, ship the 128 bytes to the others, then every rank constructs
+    Comm(id, nranks, rank) — a collective call."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(load().rcdm_comm_unique_id(buf), "rcdm_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, unique_id, nranks, rank):
+        if len(unique_id) != 128:
+            raise ValueError("an RCCL unique id is 128 bytes")
+        self.nranks, self.rank = int(nranks), int(rank)
+        self.comm = C.c_void_p(0)
+        _check(load().rcdm_comm_create(C.create_string_buffer(bytes(unique_id), 128), self.nranks, self.rank,
+                                       C.byref(self.comm)), "rcdm_comm_create")
+
+    def bcast(self, ptr, nbytes, root=0, stream=None):
+        _check(load().rcdm_bcast(self.comm, ptr, nbytes, root, stream_ptr() if stream is None else stream), "rcdm_bcast")
+
+    def allgather(self, send_ptr, recv_ptr, bytes_per_rank, stream=None):
+        _check(load().rcdm_allgather(self.comm, send_ptr, recv_ptr, bytes_per_rank,
+                                     stream_ptr() if stream is None else stream), "rcdm_allgather")
+
+    def close(self):
+        if self.comm:
+            load().rcdm_comm_destroy(self.comm)
+            self.comm = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            if _lib is not None:
+                self.close()
         except Exception:
             pass
 

@@ -13,7 +13,11 @@ from .engine import CIN_PAD
 
 class DenoiseLoop:
     def __init__(self, unet, stories, frames, height, width, ctx_len, guidance_scale, scheduler, num_steps,
-                 share_cfg_prefix=True):
+                 share_cfg_prefix=True, cfg_split=None):
+        """cfg_split (rcdms_amd.dist.CfgSplit or anything with .half and .allgather(send_ptr, recv_ptr, nbytes)): the
+        two-GPUs-per-story latency mode — this rank evaluates only CFG half `half` of the UNet (batch S instead of 2S),
+        the halves' noise predictions are all-gathered inside the step graph and every rank applies the same CFG +
+        DDIM update.  load() still takes the full CFG batch of mask / masked latents / context."""
         self.unet, self.S, self.f, self.H, self.W = unet, stories, frames, height, width
         self.gs = float(guidance_scale)
         self.reps = 2 if guidance_scale > 1.0 else 1
@@ -54,7 +58,10 @@ class DenoiseLoop:
         # Two launch plans, built on first use: the general one, and the "shared prefix" one for the case the reference
         # pipeline always produces under CFG (RCDMs_pipeline.py:481-482: latents, mask and masked latents of the two
         # halves are the same tensors) where the part of the UNet ahead of the first cross-attention is evaluated once.
-        self.share_allowed = share_cfg_prefix
+        self.split = cfg_split
+        if cfg_split is not None and self.reps != 2:
+            raise ValueError("cfg_split needs classifier-free guidance (guidance_scale > 1)")
+        self.share_allowed = share_cfg_prefix and cfg_split is None
         self._variants = {}
         self._v = None
 
@@ -62,18 +69,39 @@ class DenoiseLoop:
         v = self._variants.get(share)
         if v is None:
             S, R, f, H, W = self.S, self.reps, self.f, self.H, self.W
-            b = R * S
-            p = self.unet.program(b, f, H, W, self.ctx_len, shared_prefix=share)
-            pre = [
-                lambda: hip.load_timestep(self.ts_dev.data_ptr(), self.step_dev.data_ptr(), p.t_dev.data_ptr(), b),
-                lambda: hip.assemble_input(self.lat.data_ptr(), self.mask.data_ptr(), self.masked.data_ptr(), S, R, f, H, W,
-                                           p.x_in.ptr, p.x_in.ld, CIN_PAD),
-            ]
-            post = [
-                lambda: hip.cfg_ddim_step(p.eps_out.ptr, p.eps_out.ld, self.lat.data_ptr(), S, R, f, H, W, self.gs,
-                                          self.coef.data_ptr(), self.step_dev.data_ptr()),
-                lambda: hip.advance_step(self.step_dev.data_ptr()),
-            ]
+            if self.split is not None:
+                # one CFG half here: batch rows [half * S, (half + 1) * S) of the reference's cat([latents] * 2)
+                half, b = self.split.half, S
+                p = self.unet.program(b, f, H, W, self.ctx_len, shared_prefix=False)
+                eps = p.eps_out
+                nbytes = eps.M * eps.ld * 2
+                self.eps_full = torch.empty(2 * eps.M, eps.ld, dtype=torch.float16, device=self.device)
+                m_off = half * S * f * H * W * 4          # fp32 (R*S, 1, f, H, W)
+                k_off = half * S * 4 * f * H * W * 4      # fp32 (R*S, 4, f, H, W)
+                pre = [
+                    lambda: hip.load_timestep(self.ts_dev.data_ptr(), self.step_dev.data_ptr(), p.t_dev.data_ptr(), b),
+                    lambda: hip.assemble_input(self.lat.data_ptr(), self.mask.data_ptr() + m_off,
+                                               self.masked.data_ptr() + k_off, S, 1, f, H, W, p.x_in.ptr, p.x_in.ld, CIN_PAD),
+                ]
+                post = [
+                    lambda: self.split.allgather(eps.ptr, self.eps_full.data_ptr(), nbytes),
+                    lambda: hip.cfg_ddim_step(self.eps_full.data_ptr(), eps.ld, self.lat.data_ptr(), S, R, f, H, W, self.gs,
+                                              self.coef.data_ptr(), self.step_dev.data_ptr()),
+                    lambda: hip.advance_step(self.step_dev.data_ptr()),
+                ]
+            else:
+                b = R * S
+                p = self.unet.program(b, f, H, W, self.ctx_len, shared_prefix=share)
+                pre = [
+                    lambda: hip.load_timestep(self.ts_dev.data_ptr(), self.step_dev.data_ptr(), p.t_dev.data_ptr(), b),
+                    lambda: hip.assemble_input(self.lat.data_ptr(), self.mask.data_ptr(), self.masked.data_ptr(), S, R, f, H, W,
+                                               p.x_in.ptr, p.x_in.ld, CIN_PAD),
+                ]
+                post = [
+                    lambda: hip.cfg_ddim_step(p.eps_out.ptr, p.eps_out.ld, self.lat.data_ptr(), S, R, f, H, W, self.gs,
+                                              self.coef.data_ptr(), self.step_dev.data_ptr()),
+                    lambda: hip.advance_step(self.step_dev.data_ptr()),
+                ]
             v = self._variants[share] = dict(prog=p, pre=pre, post=post, graph=None)
         self.shared = share
         self._v = v
@@ -115,6 +143,9 @@ class DenoiseLoop:
         share = (self.share_allowed and R == 2 and bool(torch.equal(self.mask[:S], self.mask[S:]))
                  and bool(torch.equal(self.masked[:S], self.masked[S:])))
         self._select(share)
+        if self.split is not None:
+            n = S * self.f                          # context rows per CFG half: (R*S*f, L, D), unconditional half first
+            ctx = ctx[self.split.half * n:(self.split.half + 1) * n]
         self.prog.set_context(ctx, force=True)   # ~3 MB + 16 small GEMMs per story: never trust a cache here
         self.step_dev.zero_()
         torch.cuda.current_stream(self.device).synchronize()

@@ -99,3 +99,59 @@ def test_bench_world_size_mismatch_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-cpu"], capture_output=True,
                        text=True, timeout=120, env=env, cwd=root)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+# ---- CFG-split latency mode: pairing, id exchange and the split step's data flow ---------------------
+
+def test_cfg_split_layout():
+    from rcdms_amd.dist import cfg_split_layout
+    assert [cfg_split_layout(4, r) for r in range(4)] == [(0, 0, 1), (0, 1, 0), (1, 0, 3), (1, 1, 2)]
+    import pytest
+    for world, rank in [(1, 0), (3, 0), (0, 0), (4, 4)]:
+        with pytest.raises(ValueError):
+            cfg_split_layout(world, rank)
+
+
+def _split_worker(rank, world, port, q):
+    from rcdms_amd.dist import cfg_split_layout, cfg_split_reference_step, exchange_unique_id
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pair, half, partner = cfg_split_layout(world, rank)
+        uid = exchange_unique_id(lambda: bytes([rank + 1]) * 128, world, rank)   # even ranks draw; both members get it
+        # a toy noise predictor with the one property the split relies on: batch rows do not interact
+        g = torch.Generator().manual_seed(7)
+        Wm = torch.randn(6, 6, generator=g)
+        eps_fn = lambda x, c: torch.tanh(x @ Wm) * c.mean(dim=1, keepdim=True)
+        x = torch.randn(3, 6, generator=g)
+        ctx_u, ctx_c = torch.randn(3, 4, generator=g), torch.randn(3, 4, generator=g)
+        for _ in range(3):                                                        # three "denoising steps"
+            eu, ec = cfg_split_reference_step(eps_fn, x, ctx_u, ctx_c, half,
+                                              lambda outs, mine: dist.all_gather(outs, mine))
+            x = x - 0.1 * (eu + 2.0 * (ec - eu))
+        # the unsplit loop on every rank, for comparison
+        y = torch.randn(3, 6, generator=torch.Generator().manual_seed(7).manual_seed(7))
+        g2 = torch.Generator().manual_seed(7)
+        torch.randn(6, 6, generator=g2)
+        y = torch.randn(3, 6, generator=g2)
+        for _ in range(3):
+            both = eps_fn(torch.cat([y, y]), torch.cat([ctx_u, ctx_c]))
+            eu, ec = both.chunk(2)
+            y = y - 0.1 * (eu + 2.0 * (ec - eu))
+        q.put((rank, pair, half, partner, uid[0], torch.equal(x, y)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg_split_step_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, 0, 0, 1, 1, True), (1, 0, 1, 0, 1, True)]

@@ -1,0 +1,120 @@
+"""The thin RCCL layer of the C-ABI (rcdm_comm_*, rcdm_bcast, rcdm_allgather) and the CFG-split latency mode of the
+denoising loop (two GPUs per story, one classifier-free-guidance half each; reference arithmetic
+RCDMs_pipeline.py:482-497).  A GPU box here has ONE device, so the collectives run on a one-rank communicator (a one-rank
+all-gather is a device copy through RCCL) and the two halves of the split loop run on the same device in lockstep; the
+two-process wiring (pairing, id exchange) is covered on CPU in test_dist_gloo.py."""
+import pytest
+import torch
+
+from rcdms_amd import synth
+from tests.test_hip_unet import DEV, build, check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def comm1(hiplib):
+    from rcdms_amd import hip
+    c = hip.Comm(hip.Comm.unique_id(), 1, 0)
+    yield c
+    c.close()
+
+
+def test_one_rank_bcast_and_allgather(comm1):
+    x = torch.arange(4096, dtype=torch.float32, device=DEV)
+    y = torch.zeros(2, 4096, dtype=torch.float32, device=DEV)
+    comm1.bcast(x.data_ptr(), x.numel() * 4, root=0)
+    comm1.allgather(x.data_ptr(), y.data_ptr() + 4096 * 4, 4096 * 4)       # "my slot" may be anywhere in recv
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu(), torch.arange(4096, dtype=torch.float32))
+    assert torch.equal(y[1], x) and not y[0].any()
+
+
+def test_allgather_inside_a_captured_graph(comm1):
+    from rcdms_amd import hip
+    x = torch.ones(1 << 16, dtype=torch.float16, device=DEV)
+    y = torch.zeros_like(x)
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        comm1.allgather(x.data_ptr(), y.data_ptr(), x.numel() * 2)        # once outside capture (lazy init)
+        st.synchronize()
+        y.zero_()
+        g = hip.Graph()
+        g.begin()
+        try:
+            comm1.allgather(x.data_ptr(), y.data_ptr(), x.numel() * 2)
+        finally:
+            g.end()
+        st.synchronize()
+        assert not y.any()                                                  # capture did not execute
+        for k in (2.0, 3.0):
+            x.fill_(k)
+            g.launch()
+            st.synchronize()
+            assert torch.equal(y, x)
+
+
+def test_bad_arguments(hiplib):
+    from rcdms_amd import hip
+    with pytest.raises(ValueError):
+        hip.Comm(b"short", 1, 0)
+    with pytest.raises(hip.RcdmError, match="RCDM_EINVAL"):
+        hip.Comm(bytes(128), 1, 1)                                          # rank outside [0, nranks)
+
+
+def test_cfg_split_loop_equals_unsplit_loop(comm1):
+    """Half 0 and half 1 of the split loop, each with batch S, in lockstep on one device — every exchange a one-rank
+    RCCL all-gather into the right slot of BOTH ranks' gathered buffers — against the ordinary loop with batch 2S.
+    Not bitwise (tile shapes follow M), so within the tolerance of 'a story of a batch vs the story alone'."""
+    from rcdms_amd.dist import CfgSplit
+    from rcdms_amd.sampler import DenoiseLoop
+    from rcdms_amd.scheduler import DDIMScheduler
+    m, m_other = build("unet_tiny"), build("unet_tiny")   # two "ranks": programs (buffers, context) are cached per module
+    S, steps = 2, 3
+    s = synth.synthetic_story(stories=S, latent_hw=(16, 16), ctx_len=13, ctx_dim=64, cfg=True, seed=21)
+    s["masked_latents"][S:] += 0.05                                        # make the halves' inputs really differ
+    mk = lambda: DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    ref_loop = DenoiseLoop(m, S, 5, 16, 16, 13, 2.0, mk(), steps)
+    ref_loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+    ref = ref_loop.run().clone()
+
+    sent = []
+    halves = [DenoiseLoop(mod, S, 5, 16, 16, 13, 2.0, mk(), steps,
+                          cfg_split=CfgSplit(h, lambda a, b, n, h=h: sent.append((h, a, b, n))))
+              for h, mod in ((0, m), (1, m_other))]
+    for lp in halves:
+        lp.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+        assert lp.prog.b == S and lp.shared is False
+    st = halves[0].prog.stream
+    with torch.cuda.stream(st):
+        for _ in range(steps):
+            for lp in halves:
+                for op in lp._pre:
+                    op()
+                lp.prog.run_body()
+            for lp in halves:                                               # what rcdm_allgather does across the pair
+                lp._post[0]()
+            assert [h for h, *_ in sent] == [0, 1]
+            (_, a0, _, n0), (_, a1, _, n1) = sent
+            assert n0 == n1 == halves[0].prog.eps_out.M * halves[0].prog.eps_out.ld * 2
+            for lp in halves:
+                comm1.allgather(a0, lp.eps_full.data_ptr(), n0)
+                comm1.allgather(a1, lp.eps_full.data_ptr() + n0, n0)
+            sent.clear()
+            for lp in halves:
+                for op in lp._post[1:]:
+                    op()
+        st.synchronize()
+    assert torch.equal(halves[0].lat, halves[1].lat)                        # both ranks hold the same story state
+    check(halves[0].lat, ref.cpu(), 3.5e-3, 5e-3, "CFG-split loop vs batch-2S loop")
+
+
+def test_cfg_split_needs_guidance(hiplib):
+    from rcdms_amd.dist import CfgSplit
+    from rcdms_amd.sampler import DenoiseLoop
+    from rcdms_amd.scheduler import DDIMScheduler
+    m = build("unet_tiny")
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    with pytest.raises(ValueError, match="guidance"):
+        DenoiseLoop(m, 1, 5, 16, 16, 13, 1.0, sched, 2, cfg_split=CfgSplit(0, lambda *a: None))

@@ -20,5 +20,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     res[c] = {"kb_per_step_raw": tot / steps, "by_kernel_kb_per_step": {k: round(v / steps) for k, v in sorted(per.items(), key=lambda kv: -kv[1])}}
 fetch = res["FETCH_SIZE"]["kb_per_step_raw"] * 1024 * 2   # gfx950: double the wide-read count
 write = res["WRITE_SIZE"]["kb_per_step_raw"] * 1024
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rcdms_amd import build as rbuild  # noqa: E402
 print(json.dumps({"hbm_bytes_per_unet_step": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
-                  "steps_in_run": steps, "raw": res}, indent=1))
+                  "steps_in_run": steps, "csrc_stamp": rbuild._stamp(),   # bench.py drops the record when the kernels change
+                  "raw": res}, indent=1))
