@@ -262,6 +262,11 @@ int rcdm_cfg_unclip_step(const void* pred, int32_t ld, float* latents, int32_t n
 int rcdm_load_timestep(const float* timesteps, const int32_t* step_counter, float* t_out,
                        int32_t rows, void* stream);
 int rcdm_advance_step(int32_t* step_counter, void* stream);
+/* dst[0..row_floats) = table[*step_counter][0..row_floats) (fp32): the per-step row of a table computed once per
+ * schedule — the whole timestep-embedding chain of unet.py:381-389 and the 22 time_emb_proj outputs (resnet.py:191)
+ * depend on the timestep only, so the sampling loop evaluates them for all T steps when the schedule is set and a
+ * captured step starts with this one copy instead of five serial launches.  row_floats % 4 == 0, 16-byte aligned. */
+int rcdm_load_table_row(const float* table, const int32_t* step_counter, float* dst, size_t row_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight repacking (fp32 reference layout -> f16 kernel layout), device to device:

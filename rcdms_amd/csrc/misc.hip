@@ -195,6 +195,12 @@ __global__ void load_timestep_kernel(const float* __restrict__ ts, const int* __
   const int i = threadIdx.x;
   if (i < rows) t_out[i] = ts[*step];
 }
+__global__ void load_table_row_kernel(const float* __restrict__ table, const int* __restrict__ step, float* __restrict__ dst,
+                                      size_t row_floats) {
+  const f32x4* src = (const f32x4*)(table + (size_t)(*step) * row_floats);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_floats / 4; i += (size_t)gridDim.x * blockDim.x)
+    ((f32x4*)dst)[i] = src[i];
+}
 __global__ void advance_step_kernel(int* step) {
   if (threadIdx.x == 0) *step = *step + 1;
 }
@@ -326,6 +332,16 @@ int rcdm_cfg_unclip_step(const void* pred, int32_t ld, float* latents, int32_t n
 int rcdm_load_timestep(const float* timesteps, const int32_t* step_counter, float* t_out, int32_t rows, void* stream) {
   if (!timesteps || !step_counter || !t_out || rows <= 0 || rows > 64) return RCDM_EINVAL;
   hipLaunchKernelGGL(load_timestep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, timesteps, step_counter, t_out, rows);
+  return rcdm_check_launch();
+}
+
+int rcdm_load_table_row(const float* table, const int32_t* step_counter, float* dst, size_t row_floats, void* stream) {
+  if (!table || !step_counter || !dst || row_floats == 0 || (row_floats & 3)) return RCDM_EINVAL;
+  if (((uintptr_t)table | (uintptr_t)dst) & 15) return RCDM_EINVAL;
+  size_t blocks = (row_floats / 4 + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(load_table_row_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, step_counter,
+                     dst, row_floats);
   return rcdm_check_launch();
 }
 

@@ -538,6 +538,10 @@ class UNetProgram:
         small_linear_rows(temb0, boc[0], te_w1, te_b1, ted, 0, 1, temb1)
         small_linear_rows(temb1, ted, te_w2, te_b2, ted, 0, 0, emb)
         small_linear_rows(emb, ted, tp_w, tp_b, tp_total, 1, 0, tproj)
+        # everything above depends on the timestep only: a sampling loop evaluates it for all T steps up front
+        # (time_table) and replays the body from here with one table-row copy in front (sampler.DenoiseLoop)
+        self.n_time_ops = len(plan.ops)
+        self.tproj = tproj
 
         def temb_of(p):
             return (tproj, tp_off[p], tp_total)
@@ -722,11 +726,25 @@ class UNetProgram:
         self.ctx_key = (ctx, ver) if ver is not None else None
 
     # ---- execution -------------------------------------------------------------------------------
-    def run_body(self):
-        """Enqueue the UNet body on torch's current stream (inputs: x_in rows, t_dev; output: eps_out)."""
-        self.plan.run()
+    def run_body(self, skip_time=False):
+        """Enqueue the UNet body on torch's current stream (inputs: x_in rows, t_dev; output: eps_out).  skip_time: the
+        time-embedding chain is left out — `tproj` already holds this step's time_emb_proj rows."""
+        self.plan.run(self.plan.ops[self.n_time_ops:] if skip_time else None)
 
-    def capture(self, pre=None, post=None):
+    def time_table(self, timesteps):
+        """[T][b * tp_total] fp32: the time_emb_proj rows of all resnets (unet.py:381-389, resnet.py:191) for each of
+        the given timesteps, every batch row at the same timestep (what the sampling loop feeds, RCDMs_pipeline.py:483)."""
+        rows = []
+        with torch.cuda.stream(self.stream):
+            for t in timesteps:
+                self.t_dev.fill_(float(t))
+                self.plan.run(self.plan.ops[:self.n_time_ops])
+                rows.append(self.tproj.reshape(-1).clone())
+            table = torch.stack(rows).contiguous()
+        self.stream.synchronize()
+        return table
+
+    def capture(self, pre=None, post=None, skip_time=False):
         """Capture [pre ops] + body + [post ops] into a hipGraph on the program's stream."""
         torch.cuda.synchronize(self.device)
         with torch.cuda.stream(self.stream):
@@ -735,7 +753,7 @@ class UNetProgram:
             try:
                 for op in (pre or []):
                     op()
-                self.plan.run()
+                self.run_body(skip_time)
                 for op in (post or []):
                     op()
             finally:

@@ -88,6 +88,7 @@ SYMBOLS = {
     "rcdm_cfg_unclip_step": (C.c_int, [_P, _I, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P]),
     "rcdm_load_timestep": (C.c_int, [_P, _P, _P, _I, _P]),
     "rcdm_advance_step": (C.c_int, [_P, _P]),
+    "rcdm_load_table_row": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "rcdm_pack_f16": (C.c_int, [_P, _P, _SZ, _P]),
     "rcdm_mish": (C.c_int, [_P, _P, _SZ, _P]),
     "rcdm_pack_conv3x3": (C.c_int, [_P, _I, _I, _I, _P, _P]),
@@ -255,6 +256,11 @@ def cfg_ddim_step(eps, ld, lat, S, reps, frames, H, W, gs, coef, step, stream=No
 def load_timestep(ts, step, t_out, rows, stream=None):
     _check(load().rcdm_load_timestep(ts, step, t_out, rows, stream_ptr() if stream is None else stream),
            "rcdm_load_timestep")
+
+
+def load_table_row(table, step, dst, row_floats, stream=None):
+    _check(load().rcdm_load_table_row(table, step, dst, row_floats, stream_ptr() if stream is None else stream),
+           "rcdm_load_table_row")
 
 
 def advance_step(step, stream=None):

@@ -2,7 +2,8 @@
 
 Reference: the `for t in timesteps` body of RCDMsPipeline.__call__ (src/pipelines/RCDMs_pipeline.py:480-503):
 cat([latents]*2) -> cat([x, mask, masked_latents], 1) -> unet -> CFG combine -> scheduler.step.  Here one graph
-holds [load t | assemble the 9-channel rows | ~10^3 UNet kernels | fused CFG+DDIM update | step++]; the step index
+holds [this step's time_emb_proj rows from a per-schedule table | assemble the 9-channel rows | ~10^3 UNet kernels |
+fused CFG+DDIM update | step++]; the step index
 and the coefficient table live in device memory, so the host issues exactly one hipGraphLaunch per step and never
 touches a parameter.  Generalised over the reference's hard-coded batch 1 / 64x64 (:408,:476) to S stories."""
 import torch
@@ -78,8 +79,9 @@ class DenoiseLoop:
                 self.eps_full = torch.empty(2 * eps.M, eps.ld, dtype=torch.float16, device=self.device)
                 m_off = half * S * f * H * W * 4          # fp32 (R*S, 1, f, H, W)
                 k_off = half * S * 4 * f * H * W * 4      # fp32 (R*S, 4, f, H, W)
+                table = p.time_table(self.timesteps.tolist())
                 pre = [
-                    lambda: hip.load_timestep(self.ts_dev.data_ptr(), self.step_dev.data_ptr(), p.t_dev.data_ptr(), b),
+                    lambda: hip.load_table_row(table.data_ptr(), self.step_dev.data_ptr(), p.tproj.data_ptr(), table.shape[1]),
                     lambda: hip.assemble_input(self.lat.data_ptr(), self.mask.data_ptr() + m_off,
                                                self.masked.data_ptr() + k_off, S, 1, f, H, W, p.x_in.ptr, p.x_in.ld, CIN_PAD),
                 ]
@@ -92,8 +94,10 @@ class DenoiseLoop:
             else:
                 b = R * S
                 p = self.unet.program(b, f, H, W, self.ctx_len, shared_prefix=share)
+                # the timestep-embedding chain and all time_emb_proj rows for the T steps of the schedule, once
+                table = p.time_table(self.timesteps.tolist())
                 pre = [
-                    lambda: hip.load_timestep(self.ts_dev.data_ptr(), self.step_dev.data_ptr(), p.t_dev.data_ptr(), b),
+                    lambda: hip.load_table_row(table.data_ptr(), self.step_dev.data_ptr(), p.tproj.data_ptr(), table.shape[1]),
                     lambda: hip.assemble_input(self.lat.data_ptr(), self.mask.data_ptr(), self.masked.data_ptr(), S, R, f, H, W,
                                                p.x_in.ptr, p.x_in.ld, CIN_PAD),
                 ]
@@ -126,7 +130,7 @@ class DenoiseLoop:
     def _one_step_eager(self):
         for op in self._pre:
             op()
-        self.prog.run_body()
+        self.prog.run_body(skip_time=True)
         for op in self._post:
             op()
 
@@ -168,7 +172,7 @@ class DenoiseLoop:
                 self.lat.copy_(lat0)
                 self.step_dev.zero_()
                 p.stream.synchronize()
-                self.graph = p.capture(pre=self._pre, post=self._post)
+                self.graph = p.capture(pre=self._pre, post=self._post, skip_time=True)
             self.step_dev.fill_(start)
             for i in range(start, stop):
                 if use_graph:
