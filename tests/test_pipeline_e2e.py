@@ -125,4 +125,4 @@ def test_pipeline_five_captions_matches_oracle_flow(hiplib, hip_vae):
     want = (want.reshape(1, 5, 3, H, W).permute(0, 2, 1, 3, 4) / 2 + 0.5).clamp(0, 1)
     r = rel_rms(out.float(), want)
     print(f"pipeline e2e ({'hip' if hip_vae else 'stub'} vae): rel-RMS {r:.3e}")
-    assert r <= 2e-2, r
+    assert r <= (2.4e-3 if hip_vae else 9.4e-3), r            # measured 1.2e-3 (HIP VAE) / 4.7e-3 (fp32 torch stub VAE)

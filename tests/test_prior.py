@@ -87,7 +87,8 @@ def test_hip_prior_vs_reference(name):
     rel_rms = float(((out - want) ** 2).mean().sqrt() / (want ** 2).mean().sqrt())
     mx = float((out - want).abs().max() / want.abs().max())
     print(f"{name}: rel-RMS {rel_rms:.3e}  max/max|ref| {mx:.3e}")
-    assert rel_rms <= 1e-2 and mx <= 5e-2, (rel_rms, mx)          # same tolerance as the UNet-level tests
+    # measured on MI355X: 1.4e-3 / 1.2e-3 (tiny), 1.8e-3 / 1.7e-3 (20-layer full shape); bound = 2x
+    assert rel_rms <= 3.6e-3 and mx <= 3.5e-3, (rel_rms, mx)
     # second call with another timestep and noisy embedding reuses the cached context and stays finite / different
     out2 = m(x["hidden_states"] * 0.5, 21, x["proj_embedding"], x["encoder_hidden_states"], x["proj_embedding1"],
              x["mask_label"], attention_mask=x["attention_mask"], return_dict=False)[0].float().cpu()
@@ -96,7 +97,7 @@ def test_hip_prior_vs_reference(name):
         ref2 = PO.prior_forward(sd, cfg, inputs(name, E, seed)["hidden_states"] * 0.5, 21,
                                 *(inputs(name, E, seed)[k] for k in ("proj_embedding", "encoder_hidden_states",
                                                                      "proj_embedding1", "mask_label", "attention_mask")))
-        assert float(((out2 - ref2) ** 2).mean().sqrt() / (ref2 ** 2).mean().sqrt()) <= 1e-2
+        assert float(((out2 - ref2) ** 2).mean().sqrt() / (ref2 ** 2).mean().sqrt()) <= 3.6e-3
 
 
 def test_unclip_scheduler_known_answers():
@@ -146,7 +147,7 @@ def test_hip_prior_loop_vs_oracle(guidance):
     ref = PO.prior_denoise_loop(sd, cfg, UnCLIPScheduler(), lat0, *args, T, guidance, noise)
     rel = float(((out - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
     print(f"prior loop gs={guidance}: rel-RMS {rel:.3e}")
-    assert torch.isfinite(out).all() and rel <= 1e-2, rel
+    assert torch.isfinite(out).all() and rel <= 4.8e-3, rel      # measured 2.4e-3 (gs 4) / 1.4e-3 (gs 1) after 5 steps
     loop.load(lat0, *args, noise=noise)
     out2 = loop.run().clone().float().cpu()
     loop.load(lat0, *args, noise=noise)
@@ -230,4 +231,4 @@ def test_prior_pipeline_call_matches_oracle_flow():
     ref = ref * 0.415 + -0.016                                      # post_process_latents (:413-415)
     rel = float(((got - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
     print(f"prior pipeline e2e: rel-RMS {rel:.3e}")
-    assert rel <= 1e-2, rel
+    assert rel <= 5.2e-3, rel                                       # measured 2.6e-3

@@ -43,7 +43,7 @@ def test_hip_vae_decode_vs_oracle(name, cfg, n, hw):
     rel = float(((got - want) ** 2).mean().sqrt() / (want ** 2).mean().sqrt())
     mx = float((got - want).abs().max() / want.abs().max())
     print(f"vae {name}: rel-RMS {rel:.3e} max {mx:.3e}")
-    assert rel <= 1e-2 and mx <= 5e-2, (rel, mx)
+    assert rel <= 4e-3 and mx <= 4.2e-3, (rel, mx)           # measured 2.0e-3 / 2.1e-3 (tiny), 1.8e-3 / 2.0e-3 (SD-1.5 shape)
     got2 = m.decode(z.cuda()).sample.float().cpu()          # cached program, deterministic
     assert torch.equal(got, got2)
 
@@ -118,7 +118,7 @@ def test_hip_vae_encode_vs_oracle(name, cfg, n, px):
         assert got.shape == want.shape == (n, 4, px // 8, px // 8) and torch.isfinite(got).all()
         rel = float(((got - want) ** 2).mean().sqrt() / (want ** 2).mean().sqrt())
         print(f"vae encode {name} {nm}: rel-RMS {rel:.3e}")
-        assert rel <= 1e-2, (nm, rel)
+        assert rel <= 3.5e-3, (nm, rel)                      # measured 1.5e-3 .. 1.7e-3
     # posterior sampling: same generator -> same draw; equals mean + std * noise of the oracle's formula
     gen = torch.Generator(device="cuda").manual_seed(5)
     s1 = dist.sample(generator=gen)
