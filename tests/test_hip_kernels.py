@@ -306,7 +306,10 @@ def test_groupnorm(hiplib, b, f, H, W, C, cross, silu):
 @pytest.mark.parametrize("M,C,pe", [(50, 320, False), (40, 640, True), (7, 1280, True), (33, 64, False),
                                     # production-sized row counts, ragged last wave
                                     (2051, 320, False), (2400, 320, True), (2049, 640, True), (2050, 1280, False),
-                                    (2400, 1280, True), (2048, 960, False)])
+                                    (2400, 1280, True), (2048, 960, False),
+                                    # widths that do not fill the row-group kernel's lanes evenly (masked chunks), the
+                                    # widest it takes (stage-1 prior), one row, and a few thousand rows of a narrow matrix
+                                    (97, 768, False), (970, 2048, False), (1, 200, False), (5000, 72, False), (20, 1000, True)])
 def test_layernorm(hiplib, M, C, pe):
     from rcdms_amd import hip
     g = torch.Generator().manual_seed(11 + C)

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rcdms_amd import hip  # noqa: E402
 
 DEV = "cuda"
+SPLIT_K = 0   # --split: forced split-K factor of the GEMM rows (0 = the library's heuristic)
 
 
 def timeit(fn, rounds=5, inner=10):
@@ -86,7 +87,7 @@ def bench_gemm(variants, rounds):
         for v in variants:
             hip.set_igemm_pingpong(v != -2)      # -2: the shape heuristic with the ping-pong kernel switched off
             hip.set_igemm_variant(max(v, -1))
-            d = hip.GemmDesc(M, N, K, K, nout, nout, epi, 1, 0, 1.0, 0)
+            d = hip.GemmDesc(M, N, K, K, nout, nout, epi, 1, 0, 1.0, SPLIT_K)
             wsb = hip.gemm_workspace_bytes(d)
             ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
             fn = lambda: hip.gemm(d, A.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, res.data_ptr(), out.data_ptr(),
@@ -190,10 +191,12 @@ if __name__ == "__main__":
     ap.add_argument("--variants", default="1,2")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="", help="substring filter on the shape name")
+    ap.add_argument("--split", type=int, default=0, help="force the GEMMs' split-K factor")
     a = ap.parse_args()
     if a.only:
         GEMMS[:] = [g for g in GEMMS if a.only in g[0]]
         CONVS[:] = [c for c in CONVS if a.only in c[0]]
+    SPLIT_K = a.split
     vs = [int(v) for v in a.variants.split(",")]
     if a.what in ("gemm", "all"):
         bench_gemm(vs, a.rounds)
