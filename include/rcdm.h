@@ -174,6 +174,17 @@ int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const
 int rcdm_flash_attn_masked(const rcdm_attn_desc* d, const void* Q, const void* K, const void* V,
                            const unsigned char* key_valid, int32_t causal, void* out, void* stream);
 
+/* Cross-attention with a short key sequence (Lk <= 96): CrossAttention.forward with encoder_hidden_states,
+ * attention.py:139-168, at the 85 / 91 context rows of the stage-2 UNet.  A wave holds all scores of 32 queries of one
+ * head in registers (no key loop, no online rescale); a block of 8 waves shares one head's operands through LDS.  K and V are passed as the per-context FRAGMENT-MAJOR image rcdm_xattn_pack_kv
+ * writes once per context (they do not change over the denoising steps): every MFMA operand fragment is one contiguous
+ * 1-KiB block in lane order; rcdm_xattn_image_bytes sizes it.  `d` is the rcdm_attn_desc of the equivalent
+ * rcdm_flash_attn call (ldk / ldv unused by rcdm_xattn); results agree with rcdm_flash_attn to f16 rounding. */
+size_t rcdm_xattn_image_bytes(int32_t batch, int32_t heads, int32_t d);
+int rcdm_xattn_pack_kv(const void* K, const void* V, int32_t batch, int32_t Lk, int32_t heads, int32_t d, int32_t ldk,
+                       int32_t ldv, void* image, void* stream);
+int rcdm_xattn(const rcdm_attn_desc* d, const void* Q, const void* image, void* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Temporal self-attention over the f frames of every (sample, pixel, head).
  *   replaces VersatileAttention.forward motion_module.py:294-354 between to_q/k/v and to_out: the

@@ -382,6 +382,178 @@ int launch_flash(const AttnArgs& a_in, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cross-attention with a short key sequence (Lk <= 96: the 85 / 91 context rows of the stage-2 UNet, attention.py:
+// 139-168 with encoder_hidden_states).  The flash kernel above is built for long key loops (LDS ping-pong images, one
+// barrier per 64-key tile, online rescale); on two tiles it is a chain of latencies.  Here nothing is staged and
+// nothing is shared: a wave owns 32 queries of ONE head and holds all 96 (padded) scores in registers —
+//   S^T = K Q^T     K fragments straight from global memory,
+//   softmax         one pass, lane-local + one exchange with lane ^ 32, no running max,
+//   O^T = V^T P^T   V^T fragments straight from global memory, a row of ones behind the head's last dim so the row sum
+//                   falls out of the same MFMA (consistent with the rounded P).
+// K and V of the context do not change over the denoising steps, so rcdm_xattn_pack_kv writes them ONCE per context as
+// a FRAGMENT-MAJOR image: every MFMA operand fragment is one contiguous 1-KiB block in lane order (lane l's eight halfs
+// at byte 16 l), i.e. one fully coalesced load instruction.  (A first version read the fragments out of the row-major
+// K and a [dim][key] V^T: 32 rows x 32 bytes per instruction — 25 % of every cache line used, the L1 thrashing — and was
+// SLOWER than the flash kernel at every level: 37 / 27 / 25 us against 29 / 18 / 12.)  The V^T fragments hold the keys
+// of every 16-group in the order the S^T accumulator registers hold P.
+// One barrier: a block is 8 waves x 32 queries of one (batch, head); the head's fragment image (21 KB at d = 40) is copied
+// into LDS once per block and every wave reads its operands from there with conflict-free lane-linear ds_read_b128.
+// (Measured and dropped: one head per WAVE with each wave fetching the image itself — 215 MB of L2 -> CU traffic per
+// launch at the 64x64 level, 25 us; the block's Q / O rows staged through LDS for whole-row accesses — two more
+// barriers, 27 us.)
+struct XAttnArgs {
+  const f16* Q;
+  const f16* KF;  // [batch][heads][3 key tiles][DS][64 lanes][8]
+  const f16* VF;  // [batch][heads][DF dim tiles][6 key steps][64 lanes][8]
+  f16* O;
+  int batch, heads, Lq, Lk, d;
+  int ldq, ldo;
+  float c;  // scale * log2(e)
+};
+
+template <int DS, int NW>
+__global__ __launch_bounds__(NW * 64) void xattn_kernel(const XAttnArgs p) {
+  constexpr int DF = (DS + 1) / 2;
+  constexpr int NFRAG = 3 * DS + 6 * DF;  // 1-KiB operand fragments of one (batch, head): K then V^T
+  extern __shared__ __attribute__((aligned(16))) char xa_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, hi = lane >> 5;
+  // a block = 8 waves x 32 queries of ONE (batch, head): its fragment image is copied to LDS once and read by all
+  // eight (every wave fetching its own copy from L2 — 21 KB per 32 queries at d = 40 — ran at the L2 -> CU delivery limit)
+  constexpr int BQ = NW * 32;
+  const int nqb = (p.Lq + BQ - 1) / BQ;
+  const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int q = qb * BQ + wave * 32 + lr;
+  const bool q_ok = q < p.Lq;
+  const bool ones_row = p.d < 32 * DF;
+  constexpr f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  {
+    const uint4* srck = (const uint4*)(p.KF + (size_t)bh * 3 * DS * 512);
+    const uint4* srcv = (const uint4*)(p.VF + (size_t)bh * 6 * DF * 512);
+    for (int it = threadIdx.x; it < NFRAG * 64; it += NW * 64)
+      ((uint4*)xa_smem)[it] = it < 3 * DS * 64 ? srck[it] : srcv[it - 3 * DS * 64];
+  }
+  f16x8 qf[DS];
+  const f16* qrow = p.Q + ((size_t)b * p.Lq + (q_ok ? q : 0)) * p.ldq + h * p.d;
+#pragma unroll
+  for (int s = 0; s < DS; ++s) {
+    const int dc = s * 16 + hi * 8;
+    Pack16 v;
+    v.u = make_uint4(0, 0, 0, 0);
+    if (q_ok && dc < p.d) v.u = *(const uint4*)(qrow + dc);
+    qf[s] = v.h;
+  }
+  __syncthreads();
+  if (qb * BQ + wave * 32 >= p.Lq) return;  // a wave past the last query (no barrier follows)
+  const char* frag = xa_smem + lane * 16;
+
+  // ---- S^T: three 32-key tiles
+  f32x16 sacc[3];
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int s = 0; s < DS; ++s)
+      sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(frag + (kt * DS + s) * 1024), qf[s],
+                                                        s == 0 ? zero : sacc[kt], 0, 0, 0);
+
+  // ---- softmax over the <= 96 keys of this lane's query: register r of tile kt is key 32 kt + (r&3) + 8 (r>>2) + 4 hi
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (key >= p.Lk) sacc[kt][r] = -INFINITY;
+      mx = fmaxf(mx, sacc[kt][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m = mx * p.c;  // Lk >= 1: at least one key is visible, m is finite
+  f16x8 pf[6];
+  float lsum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], p.c, -m));
+      const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r + 1], p.c, -m));
+      if (!ones_row) lsum += p0 + p1;
+      const auto pk = __builtin_amdgcn_cvt_pkrtz(p0, p1);
+      pf[kt * 2 + (r >> 3)][r & 7] = (f16)pk[0];
+      pf[kt * 2 + (r >> 3)][(r & 7) + 1] = (f16)pk[1];
+    }
+
+  // ---- O^T = V^T P^T: six steps of 16 keys per dim tile
+  f32x16 oacc[DF];
+#pragma unroll
+  for (int f = 0; f < DF; ++f)
+#pragma unroll
+    for (int st = 0; st < 6; ++st)
+      oacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(frag + (3 * DS + f * 6 + st) * 1024), pf[st],
+                                                       st == 0 ? zero : oacc[f], 0, 0, 0);
+
+  float l_tot;
+  if (ones_row) {
+    float l0 = 0.f;
+#pragma unroll
+    for (int f = 0; f < DF; ++f)
+#pragma unroll
+      for (int rr = 0; rr < 16; rr += 4)
+        if (f * 32 + rr * 2 == p.d) l0 = oacc[f][rr];
+    l_tot = __shfl(l0, lr, 64);
+  } else {
+    l_tot = lsum + __shfl_xor(lsum, 32, 64);
+  }
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (!q_ok) return;
+  f16* ob = p.O + ((size_t)b * p.Lq + q) * p.ldo + h * p.d;
+#pragma unroll
+  for (int f = 0; f < DF; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dd = f * 32 + g * 8 + hi * 4;
+      if (dd < p.d) {
+        f16x4 o = {(f16)(oacc[f][4 * g] * inv), (f16)(oacc[f][4 * g + 1] * inv), (f16)(oacc[f][4 * g + 2] * inv),
+                   (f16)(oacc[f][4 * g + 3] * inv)};
+        *(f16x4*)(ob + dd) = o;
+      }
+    }
+}
+
+// K, V [batch*Lk][ld] (head h at columns h*d ..) -> the fragment-major image: thread = one lane slot (16 bytes) of one
+// fragment; fragments of a (batch, head): 3*DS of K then 6*DF of V^T
+__global__ void xattn_pack_kv_kernel(const f16* __restrict__ K, const f16* __restrict__ V, int batch, int Lk, int heads, int d,
+                                     int ldk, int ldv, int DS, int DF, f16* __restrict__ img_k, f16* __restrict__ img_v) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_bh = (3 * DS + 6 * DF) * 64;
+  if (idx >= (size_t)batch * heads * per_bh) return;
+  const int bh = (int)(idx / per_bh), r = (int)(idx - (size_t)bh * per_bh);
+  const int frag = r >> 6, lane = r & 63, lr = lane & 31, hi = lane >> 5;
+  const int h = bh % heads, b = bh / heads;
+  union { f16 e[8]; uint4 u; } o;
+  if (frag < 3 * DS) {
+    const int kt = frag / DS, s = frag - kt * DS;
+    const int key = kt * 32 + lr, dc = s * 16 + hi * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      o.e[i] = (key < Lk && dc + i < d) ? K[((size_t)b * Lk + key) * ldk + h * d + dc + i] : (f16)0.f;
+    *(uint4*)(img_k + ((size_t)bh * 3 * DS + frag) * 512 + lane * 8) = o.u;
+  } else {
+    const int fv = frag - 3 * DS, f = fv / 6, st = fv - f * 6;
+    const int dd = f * 32 + lr;
+    const bool ones = d < 32 * DF && dd == d;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int key = 16 * st + (i < 4 ? 4 * hi + i : 8 + 4 * hi + (i - 4));
+      float v = ones ? 1.0f : 0.0f;
+      if (dd < d && key < Lk) v = (float)V[((size_t)b * Lk + key) * ldv + h * d + dd];
+      o.e[i] = (f16)v;
+    }
+    *(uint4*)(img_v + ((size_t)bh * 6 * DF + fv) * 512 + lane * 8) = o.u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // temporal attention.  A block stages the [q|k|v] rows of TPB pixels x F frames in LDS with fully coalesced
 // 16-byte loads (rows are 3C halfs contiguous), then lane (pixel, head, query frame i) computes its F scores,
 // softmax and output row from LDS, overwrites its own q segment with the result, and the block writes the
@@ -531,6 +703,69 @@ int rcdm_flash_attn_masked(const rcdm_attn_desc* d, const void* Q, const void* K
 
 int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const void* V, void* out, void* stream_) {
   return rcdm_flash_attn_masked(d, Q, K, V, nullptr, 0, out, stream_);
+}
+
+static int xattn_ds(int d) {
+  const int ds = (d + 15) / 16;
+  return ds <= 3 ? ds : ds <= 5 ? 5 : 10;
+}
+
+size_t rcdm_xattn_image_bytes(int32_t batch, int32_t heads, int32_t d) {
+  if (batch <= 0 || heads <= 0 || d <= 0 || (d & 7) || d > 160) return 0;
+  const int DS = xattn_ds(d), DF = (DS + 1) / 2;
+  return (size_t)batch * heads * (3 * DS + 6 * DF) * 1024;
+}
+
+int rcdm_xattn_pack_kv(const void* K, const void* V, int32_t batch, int32_t Lk, int32_t heads, int32_t d, int32_t ldk,
+                       int32_t ldv, void* image, void* stream_) {
+  if (!K || !V || !image || batch <= 0 || heads <= 0 || Lk <= 0 || d <= 0) return RCDM_EINVAL;
+  if ((d & 7) || d > 160 || Lk > 96 || ldk < heads * d || ldv < heads * d) return RCDM_ESHAPE;
+  const int DS = xattn_ds(d), DF = (DS + 1) / 2;
+  const size_t total = (size_t)batch * heads * (3 * DS + 6 * DF) * 64;
+  f16* img_k = (f16*)image;
+  f16* img_v = img_k + (size_t)batch * heads * 3 * DS * 512;
+  hipLaunchKernelGGL(xattn_pack_kv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                     (const f16*)K, (const f16*)V, batch, Lk, heads, d, ldk, ldv, DS, DF, img_k, img_v);
+  return rcdm_check_launch();
+}
+
+int rcdm_xattn(const rcdm_attn_desc* d, const void* Q, const void* image, void* out, void* stream_) {
+  if (!d || !Q || !image || !out) return RCDM_EINVAL;
+  if (d->batch <= 0 || d->heads <= 0 || d->Lq <= 0 || d->Lk <= 0 || d->d <= 0) return RCDM_EINVAL;
+  if ((d->d & 7) || d->d > 160 || d->Lk > 96) return RCDM_ESHAPE;
+  if ((d->ldq & 7) || (d->ldo & 3)) return RCDM_ESHAPE;
+  const int DS = xattn_ds(d->d);
+  XAttnArgs a;
+  a.Q = (const f16*)Q; a.O = (f16*)out;
+  a.KF = (const f16*)image;
+  a.VF = a.KF + (size_t)d->batch * d->heads * 3 * DS * 512;
+  a.batch = d->batch; a.heads = d->heads; a.Lq = d->Lq; a.Lk = d->Lk; a.d = d->d;
+  a.ldq = d->ldq; a.ldo = d->ldo;
+  a.c = d->scale * 1.4426950408889634f;
+  const int DF_ = (DS + 1) / 2;
+  static int nw_mode = -1;  // RCDM_XATTN_WAVES=4|8: waves (x 32 queries) per block (A/B switch)
+  if (nw_mode < 0) {
+    const char* e = getenv("RCDM_XATTN_WAVES");
+    nw_mode = e ? atoi(e) : 8;
+  }
+  const int nw = nw_mode == 4 ? 4 : 8;  // measured at the 64x64 level: 4 waves 26.7 us, 8 waves 21.2, 16 waves 23.5
+  const dim3 grid((unsigned)(d->batch * d->heads * ((d->Lq + nw * 32 - 1) / (nw * 32)))), block(nw * 64);
+  const size_t lds = (size_t)(3 * DS + 6 * DF_) * 1024;
+  hipStream_t stream = (hipStream_t)stream_;
+#define XA_LAUNCH(DS_)                                                                \
+  if (nw == 4)                                                                        \
+    hipLaunchKernelGGL((xattn_kernel<DS_, 4>), grid, block, lds, stream, a);          \
+  else                                                                                \
+    hipLaunchKernelGGL((xattn_kernel<DS_, 8>), grid, block, lds, stream, a)
+  switch (DS) {
+    case 1: XA_LAUNCH(1); break;
+    case 2: XA_LAUNCH(2); break;
+    case 3: XA_LAUNCH(3); break;
+    case 5: XA_LAUNCH(5); break;
+    default: XA_LAUNCH(10); break;
+  }
+#undef XA_LAUNCH
+  return rcdm_check_launch();
 }
 
 int rcdm_temporal_attn(const rcdm_temporal_attn_desc* d, const void* qkv, void* out, void* stream_) {

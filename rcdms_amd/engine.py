@@ -16,6 +16,7 @@ conv3x3 tap-major); cross-attention K/V of the context are computed once per con
 torch is used only for device memory, streams and host<->device copies.
 """
 import math
+import os
 
 import torch
 
@@ -182,6 +183,30 @@ def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out):
     def op():
         hip.flash_attn(d, q.ptr, k.ptr, v.ptr, out.ptr)
     plan.add(op, f"flash_attn B={batch} H={heads} Lq={Lq} Lk={Lk} d={d_head}")
+    plan.n_launch += 1
+
+
+XATTN_MAX_KEYS = 96   # rcdm_xattn: cross-attention with all scores of a query in registers
+
+
+def emit_xattn_pack(plan, k, v, batch, heads, Lk, d_head):
+    """Fragment-major K / V image of a context for rcdm_xattn (written once per context, next to its [K | V] GEMM)."""
+    img = torch.empty(hip.xattn_image_bytes(batch, heads, d_head), dtype=torch.uint8, device=plan.device)
+    plan.keep.append(img)
+
+    def op():
+        hip.xattn_pack_kv(k.ptr, v.ptr, batch, Lk, heads, d_head, k.ld, v.ld, img.data_ptr())
+    plan.add(op, f"xattn_pack B={batch} H={heads} Lk={Lk} d={d_head}")
+    plan.n_launch += 1
+    return img
+
+
+def emit_xattn(plan, q, img, batch, heads, Lq, Lk, d_head, out):
+    d = hip.AttnDesc(batch, heads, Lq, Lk, d_head, q.ld, 0, 0, out.ld, d_head ** -0.5)
+
+    def op():
+        hip.xattn(d, q.ptr, img.data_ptr(), out.ptr)
+    plan.add(op, f"xattn B={batch} H={heads} Lq={Lq} Lk={Lk} d={d_head}")
     plan.n_launch += 1
 
 
@@ -384,7 +409,7 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C):
     emit_gemm(plan, gg, ff2, C, 4 * C, tok, bias=ff2_b, residual=tok)
 
 
-def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False):
+def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False, ctx_img=None):
     """BasicTransformerBlock.forward (src/models/attention.py:479-526) in place on tok [n_seq*Lq][C]:
     h += attn1(LN1(h)); h += attn2(LN2(h), ctx); h += FF(LN3(h)).  ctx_kv: Rows [n_seq*L][2C] = [K | V] of the context.
     shared_half: the two halves of tok (the CFG halves of a denoising step) hold IDENTICAL rows on entry — everything up
@@ -407,7 +432,10 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
         emit_layernorm(plan, tok.rows(0, Ms), w.ln[1][0], w.ln[1][1], a.rows(0, Ms))
         qc = plan.rows("qkv", M, C)
         emit_gemm(plan, a.rows(0, Ms), w.q2, C, C, qc.rows(0, Ms), bias=w.q2_b, dup_rows=dup)
-        emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), n_seq, heads, Lq, L, d_head, ao)
+        if ctx_img is not None:   # short context: the per-context fragment image (emit_ctx_kv), scores in registers
+            emit_xattn(plan, qc, ctx_img, n_seq, heads, Lq, L, d_head, ao)
+        else:
+            emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), n_seq, heads, Lq, L, d_head, ao)
         emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok)
     if w.geglu:
         emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, M, C)
@@ -418,7 +446,7 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
         emit_gemm(plan, hid, w.ff2, C, 4 * C, tok, bias=w.ff2_b, residual=tok)
 
 
-def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_half=False):
+def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_half=False, ctx_img=None):
     """Transformer3DModel.forward + BasicTransformerBlock.forward (src/models/attention.py:318-365,479-526).
     ctx_kv: Rows [n_img*L][2C] = [K | V] projections of the context for this site (computed per context).
     shared_half: see emit_basic_block (x holds identical halves; both halves of `out` are still written in full)."""
@@ -428,13 +456,17 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     emit_groupnorm(plan, x.rows(0, M_s), n_s, g.hw, w.gn_g, w.gn_b, 1e-6, False, a.rows(0, M_s), groups)
     tok = plan.rows("tok", g.M, C)
     emit_gemm(plan, a.rows(0, M_s), w.proj_in, C, C, tok.rows(0, M_s), bias=w.proj_in_b)
-    emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half)
+    emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img)
     emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
 
 
-def emit_ctx_kv(plan, w, ctx16, ctx_kv):
-    """[K | V] = ctx [to_k; to_v]^T  (CrossAttention.forward attention.py:139-141) — context only."""
+def emit_ctx_kv(plan, w, ctx16, ctx_kv, n_seq=0, L=0, heads=0):
+    """[K | V] = ctx [to_k; to_v]^T  (CrossAttention.forward attention.py:139-141) — context only.  With n_seq / L /
+    heads given and L <= XATTN_MAX_KEYS, also the fragment image rcdm_xattn reads (returned; else None)."""
     emit_gemm(plan, ctx16, w.kv2, 2 * w.C, w.ctx_dim, ctx_kv, bias=getattr(w, "kv2_b", None))
+    if heads and 0 < L <= XATTN_MAX_KEYS and os.environ.get("RCDM_XATTN", "1") != "0":
+        return emit_xattn_pack(plan, ctx_kv.cols(0, w.C), ctx_kv.cols(w.C, w.C), n_seq, heads, L, w.C // heads)
+    return None
 
 
 def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
@@ -598,8 +630,8 @@ class UNetProgram:
             w = pack_transformer(pk, p)
             kv = plan.rows(f"ctx_kv{site[0]}", geo.n_img * L, 2 * w.C, unique=True)
             site[0] += 1
-            emit_ctx_kv(ctx_plan, w, self.ctx16, kv)
-            emit_transformer(plan, w, x, geo, kv, L, heads, out, groups, shared_half=shared_half)
+            img = emit_ctx_kv(ctx_plan, w, self.ctx16, kv, geo.n_img, L, heads)
+            emit_transformer(plan, w, x, geo, kv, L, heads, out, groups, shared_half=shared_half, ctx_img=img)
 
         def motion(p, x, geo, out):
             emit_motion(plan, pack_motion(pk, p, n_attn), x, geo, mheads, out, groups)
@@ -877,9 +909,9 @@ def run_tokens(kind, sd, x, ctx=None, heads=8):
             if c16 is None:
                 raise ValueError("this BasicTransformerBlock has a cross-attention: encoder_hidden_states is required")
             kv = plan.rows("ctx_kv", c16.M, 2 * C, unique=True)
-            emit_ctx_kv(plan, w, c16, kv)
+            img = emit_ctx_kv(plan, w, c16, kv, B, ctx.shape[1], heads)
         a = plan.rows("norm", M, C)
-        emit_basic_block(plan, w, tok, B, Lq, heads, a, kv, ctx.shape[1] if ctx is not None else 0)
+        emit_basic_block(plan, w, tok, B, Lq, heads, a, kv, ctx.shape[1] if ctx is not None else 0, ctx_img=img if kv is not None else None)
         res_rows = tok
     else:
         raise ValueError(kind)
@@ -925,9 +957,9 @@ def run_block(kind, sd, x, device=None, **kw):
         ctx16 = plan.rows("ctx16", geo.n_img * L, w.ctx_dim, unique=True)
         kv = plan.rows("ctx_kv", geo.n_img * L, 2 * w.C, unique=True)
         plan.add(lambda: hip.pack_f16(ctx.data_ptr(), ctx16.ptr, ctx.numel()))
-        emit_ctx_kv(plan, w, ctx16, kv)
+        img = emit_ctx_kv(plan, w, ctx16, kv, geo.n_img, L, kw["heads"])
         out = plan.rows("out", geo.M, c, unique=True)
-        emit_transformer(plan, w, xr, geo, kv, L, kw["heads"], out, groups)
+        emit_transformer(plan, w, xr, geo, kv, L, kw["heads"], out, groups, ctx_img=img)
         oc, oh, ow = c, H, W
     elif kind == "motion":
         w = pack_motion(pk, "", kw["n_attn"])

@@ -87,6 +87,9 @@ SYMBOLS = {
     "rcdm_prior_assemble": (C.c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rcdm_cfg_unclip_step": (C.c_int, [_P, _I, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P]),
     "rcdm_load_timestep": (C.c_int, [_P, _P, _P, _I, _P]),
+    "rcdm_xattn_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "rcdm_xattn_pack_kv": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "rcdm_xattn": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P]),
     "rcdm_advance_step": (C.c_int, [_P, _P]),
     "rcdm_load_table_row": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "rcdm_pack_f16": (C.c_int, [_P, _P, _SZ, _P]),
@@ -256,6 +259,19 @@ def cfg_ddim_step(eps, ld, lat, S, reps, frames, H, W, gs, coef, step, stream=No
 def load_timestep(ts, step, t_out, rows, stream=None):
     _check(load().rcdm_load_timestep(ts, step, t_out, rows, stream_ptr() if stream is None else stream),
            "rcdm_load_timestep")
+
+
+def xattn_image_bytes(batch, heads, d):
+    return load().rcdm_xattn_image_bytes(batch, heads, d)
+
+
+def xattn_pack_kv(k, v, batch, Lk, heads, d, ldk, ldv, image, stream=None):
+    _check(load().rcdm_xattn_pack_kv(k, v, batch, Lk, heads, d, ldk, ldv, image,
+                                     stream_ptr() if stream is None else stream), "rcdm_xattn_pack_kv")
+
+
+def xattn(desc, q, image, out, stream=None):
+    _check(load().rcdm_xattn(C.byref(desc), q, image, out, stream_ptr() if stream is None else stream), "rcdm_xattn")
 
 
 def load_table_row(table, step, dst, row_floats, stream=None):

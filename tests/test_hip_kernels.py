@@ -361,6 +361,49 @@ def test_flash_attn(hiplib, batch, heads, Lq, Lk, d):
     close(out.reshape(batch, Lq, C), ref)
 
 
+@pytest.mark.parametrize("batch,heads,Lq,Lk,d", [
+    (2, 8, 4096, 85, 40),    # the stage-2 cross-attention sites at 64x64 / 32x32 / 16x16 / 8x8 latents
+    (10, 8, 1024, 85, 80),
+    (2, 8, 256, 91, 160),    # FlintstonesSV context length
+    (10, 8, 64, 85, 160),
+    (1, 8, 100, 96, 40),     # ragged query count, full key capacity
+    (3, 4, 33, 1, 40),       # a single key: softmax == 1, output == V row
+    (2, 2, 70, 13, 32),      # tiny-config shapes (no spare dim row at d = 32: VALU row sum)
+    (1, 1, 5, 50, 8),
+])
+def test_xattn_short_keys(hiplib, batch, heads, Lq, Lk, d):
+    """rcdm_xattn_pack_kv + rcdm_xattn (cross-attention with Lk <= 96, scores held in registers) vs the oracle attention
+    and vs rcdm_flash_attn on the same buffers."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(11 + Lq + Lk + d)
+    C = heads * d
+    q = h16(torch.randn(batch, Lq, C, generator=g))
+    k = h16(torch.randn(batch, Lk, C, generator=g))
+    v = h16(torch.randn(batch, Lk, C, generator=g))
+    ref = O.attention_core(q, k, v, heads)
+    qd = q.reshape(-1, C).half().to(DEV)
+    kv = torch.cat([k.reshape(-1, C), v.reshape(-1, C)], dim=1).half().to(DEV)     # [K | V] rows, as the context GEMM writes
+    img = torch.empty(hip.xattn_image_bytes(batch, heads, d), dtype=torch.uint8, device=DEV)
+    out = torch.empty(batch * Lq, C, dtype=torch.float16, device=DEV)
+    out_f = torch.empty_like(out)
+    desc = hip.AttnDesc(batch, heads, Lq, Lk, d, C, 2 * C, 2 * C, C, d ** -0.5)
+    hip.xattn_pack_kv(kv.data_ptr(), kv.data_ptr() + 2 * C, batch, Lk, heads, d, 2 * C, 2 * C, img.data_ptr())
+    hip.xattn(desc, qd.data_ptr(), img.data_ptr(), out.data_ptr())
+    hip.flash_attn(desc, qd.data_ptr(), kv.data_ptr(), kv.data_ptr() + 2 * C, out_f.data_ptr())
+    torch.cuda.synchronize()
+    close(out.reshape(batch, Lq, C), ref)
+    assert (out.float() - out_f.float()).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-3
+
+
+def test_xattn_rejects_long_keys(hiplib):
+    from rcdms_amd import hip
+    desc = hip.AttnDesc(1, 8, 64, 97, 40, 320, 640, 640, 320, 40 ** -0.5)
+    x = torch.zeros(1 << 16, dtype=torch.float16, device=DEV)
+    with pytest.raises(hip.RcdmError, match="RCDM_ESHAPE"):
+        hip.xattn(desc, x.data_ptr(), x.data_ptr(), x.data_ptr())
+    assert hip.xattn_image_bytes(2, 8, 40) == 2 * 8 * (9 + 12) * 1024 and hip.xattn_image_bytes(1, 8, 160) == 8 * (30 + 30) * 1024
+
+
 @pytest.mark.parametrize("batch,heads,L,d,causal,pad", [
     (2, 4, 97, 64, True, True),      # the stage-1 prior's shape: 91 text + 6 extra tokens, causal + text padding
     (2, 4, 97, 64, True, False),

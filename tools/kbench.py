@@ -123,7 +123,9 @@ def bench_conv(variants, rounds):
 
 def bench_attn(rounds, only=""):
     for name, batch, heads, L, Lk, d in [("L0 self d=40", 10, 8, 4096, 4096, 40), ("L1 self d=80", 10, 8, 1024, 1024, 80),
-                                          ("L2 self d=160", 10, 8, 256, 256, 160), ("L0 cross Lk=85", 10, 8, 4096, 85, 40)]:
+                                          ("L2 self d=160", 10, 8, 256, 256, 160), ("L0 cross Lk=85", 10, 8, 4096, 85, 40),
+                                          ("L1 cross Lk=85", 10, 8, 1024, 85, 80), ("L2 cross Lk=85", 10, 8, 256, 85, 160),
+                                          ("L3 cross Lk=85", 10, 8, 64, 85, 160)]:
         if only and only not in name:
             continue
         C = heads * d
@@ -138,7 +140,13 @@ def bench_attn(rounds, only=""):
             fn = lambda: hip.flash_attn(desc, qkv.data_ptr(), kv.data_ptr(), kv.data_ptr() + 2 * C, out.data_ptr())
         med, mn = timeit(fn, rounds)
         fl = 4.0 * batch * heads * L * Lk * d
-        print(f"attn {name:28s} {fl / 1e9:8.1f} GF | {med:7.1f}us {fl / med / 1e6:6.0f}TF", flush=True)
+        line = f"attn {name:28s} {fl / 1e9:8.1f} GF | {med:7.1f}us {fl / med / 1e6:6.0f}TF"
+        if L != Lk and Lk <= 96:   # the short-key kernel on the same data (K / V image packed once, outside the timing)
+            img = torch.empty(hip.xattn_image_bytes(batch, heads, d), dtype=torch.uint8, device=DEV)
+            hip.xattn_pack_kv(kv.data_ptr(), kv.data_ptr() + 2 * C, batch, Lk, heads, d, 2 * C, 2 * C, img.data_ptr())
+            med2, _ = timeit(lambda: hip.xattn(desc, qkv.data_ptr(), img.data_ptr(), out.data_ptr()), rounds)
+            line += f" | rcdm_xattn {med2:7.1f}us {fl / med2 / 1e6:6.0f}TF"
+        print(line, flush=True)
     for name, b, f, px, heads, d in [("L0 temporal", 2, 5, 4096, 8, 40), ("L1 temporal", 2, 5, 1024, 8, 80)]:
         if only and only not in name:
             continue
