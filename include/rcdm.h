@@ -70,6 +70,24 @@ typedef struct {
 } rcdm_gemm_desc;
 
 size_t rcdm_gemm_workspace_bytes(const rcdm_gemm_desc* d);
+/* rcdm_gemm with the LayerNorm that follows it fused into the epilogue: out = epi(A W^T) as rcdm_gemm (bias / residual /
+ * out_scale / dup_rows), and ln->out[m][:] = LayerNorm(out[m][:]) * gamma + beta (+ pe[(m / rows_per_frame) % frames][:])
+ * computed from the f16-rounded `out` row, exactly what rcdm_layernorm would read back.  For N <= 320 (one 160x320 tile
+ * spans the row): the token-matrix GEMMs of the 64x64 level (to_out / proj_in -> norm1/2/3, attention.py:479-526,
+ * motion_module.py:234-246), where the separate LayerNorm is a 26-MB read + 26-MB write per call.  No GEGLU / GELU /
+ * row vector / split-K; no workspace. */
+typedef struct {
+  const float* gamma;
+  const float* beta;
+  const float* pe;            /* NULL, or the positional-encoding table [frames][N] (fp32) */
+  void* out;                  /* f16 [M][ld] */
+  int32_t ld;
+  int32_t rows_per_frame, frames;
+  float eps;
+} rcdm_ln_fuse;
+int rcdm_gemm_ln(const rcdm_gemm_desc* d, const rcdm_ln_fuse* ln, const void* A, const void* W, const float* bias,
+                 const void* residual, void* out, void* stream);
+
 /* tuning/test knob for rcdm_gemm and rcdm_conv3x3: -1 = automatic (default: chosen per shape; env
  * RCDM_IGEMM=dma128|dma256|dma64 overrides), tile (pixels x channels): 1 = 128x128, 2 = 256x256, 3 = 64x64,
  * 4 = 64x64 with a four-slot LDS ring, 5 = 128x64.

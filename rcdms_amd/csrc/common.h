@@ -84,6 +84,23 @@ __device__ __forceinline__ uint4 geglu8(uint4 h, uint4 g, const float (&bh)[8], 
   return o.u;
 }
 
+// sum over groups of LPR consecutive lanes (LPR a power of two, 8..64), result in every lane of the group: DPP steps
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: no LDS crossbar), ds_bpermute only across 16-lane rows
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);  // row_half_mirror: quads are uniform by now, so the mirrored partner is the other quad's sum
+  if constexpr (LPR >= 16) v += dpp_f32<0x140>(v);  // row_mirror: the other 8-lane group of the 16-lane row
+  if constexpr (LPR >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (LPR >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -984,6 +984,34 @@ int rcdm_gemm(const rcdm_gemm_desc* d, const void* A, const void* W, const float
   return launch<1>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int rcdm_gemm_ln(const rcdm_gemm_desc* d, const rcdm_ln_fuse* ln, const void* A, const void* W, const float* bias,
+                 const void* residual, void* out, void* stream) {
+  if (!d || !ln || !ln->gamma || !ln->beta || !ln->out) return RCDM_EINVAL;
+  if (ln->pe && (ln->rows_per_frame <= 0 || ln->frames <= 0)) return RCDM_EINVAL;
+  IgemmArgs a{};
+  from_gemm(d, a);
+  a.A = (const f16*)A; a.W = (const f16*)W; a.bias = bias; a.rowvec = nullptr;
+  a.res = (const f16*)residual; a.out = (f16*)out;
+  int rc = check_common(a);
+  if (rc) return rc;
+  // one 160x320 ping-pong tile must span the output row; only the plain epilogues
+  if (a.N > kPPShapes[0].bn || (ln->ld & 7) || d->split_k > 1) return RCDM_ESHAPE;
+  if (a.epi & (RCDM_EPI_GEGLU | RCDM_EPI_GELU | RCDM_EPI_ROWVEC)) return RCDM_ESHAPE;
+  a.tilesM = (a.M + kPPShapes[0].bm - 1) / kPPShapes[0].bm;
+  a.tilesN = 1;
+  a.kc = (a.Cin + BK - 1) / BK;
+  a.nk = a.kc;
+  a.splits = 1;
+  a.nk_per_split = a.nk;
+  a.partial = nullptr;
+  a.trace = nullptr;
+  a.dbg = 0;
+  a.epi |= kEpiLN;
+  a.ln_g = ln->gamma; a.ln_b = ln->beta; a.ln_pe = ln->pe; a.ln_out = (f16*)ln->out; a.ln_ld = ln->ld;
+  a.ln_rpf = ln->pe ? ln->rows_per_frame : 1; a.ln_frames = ln->pe ? ln->frames : 1; a.ln_eps = ln->eps;
+  return rcdm_igemm_pp_launch(a, 1, 0, (hipStream_t)stream);
+}
+
 size_t rcdm_conv3x3_workspace_bytes(const rcdm_conv3x3_desc* d) {
   if (!d) return 0;
   IgemmArgs a{};

@@ -24,7 +24,15 @@ struct IgemmArgs {
   int tilesM, tilesN, kc, nk, splits, nk_per_split;
   long long* trace;  // debug: per-block s_memtime stamps (rcdm_debug_set_igemm_trace), normally null
   int dbg;           // ping-pong loop switches: 8 = rotate the k order per block (RCDM_PP_ROTATE, default on)
+  // fused LayerNorm of the output rows (rcdm_gemm_ln; kEpiLN in epi, the 160x320 ping-pong tile only)
+  const float* ln_g;
+  const float* ln_b;
+  const float* ln_pe;
+  f16* ln_out;
+  int ln_ld, ln_rpf, ln_frames;
+  float ln_eps;
 };
+constexpr int kEpiLN = 1 << 20;  // internal epilogue bit (not part of the C-ABI flags)
 
 // GEGLU packing (rcdm_pack_geglu_rows): packed rows/columns come in groups of 32 = 16 "hidden" + their 16 "gate"
 // (16 = one 16x16x32 fragment, half a 32x32x16 one: value and gate sit in the same lane for both MFMA shapes, and every

@@ -10,7 +10,7 @@
 
 __device__ __forceinline__ void epi_store16(f16* dst, uint4 v) { *(uint4*)dst = v; }  // (non-temporal: measured, no change)
 
-template <int FMW, int FNW, bool SLAB, int NT, int BM, int BN>
+template <int FMW, int FNW, bool SLAB, int NT, int BM, int BN, bool LN_OK = false>
 __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f32x4 (&acc)[FNW][FMW], int cm0, int cn0,
                                               int row0, int col0, int l15, int kg, int t) {
   if constexpr (SLAB) {
@@ -98,6 +98,100 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
       constexpr int CPR = BN / 8;
       constexpr int ITEMS = BM * CPR;
       const bool has_res = (p.epi & RCDM_EPI_RESIDUAL) != 0;
+      if constexpr (LN_OK && BN >= 320 && NT == 512) {
+        if (p.epi & kEpiLN) {
+          // ---- rcdm_gemm_ln: the tile spans the whole output row (N <= BN).  Eight lanes share a row (five 16-byte chunks
+          // each, c = 8 k + l), 64 rows per pass: out = f16((acc + bias + residual) * scale) is stored, and the LayerNorm
+          // of exactly those rounded values — mean, then squared deviations, two DPP group sums — goes to ln_out.  Same
+          // arithmetic as layernorm_grp_kernel<8, 5> reading `out` back.
+          const int l = t & 7, rsub = t >> 3, nchunks = p.N >> 3;
+          const float invN = 1.0f / (float)p.N;
+          // the residual tile of ALL passes is requested first: one HBM round trip for the block instead of one per pass
+          constexpr int NPASS = (BM + 63) / 64;
+          Pack16 rall[NPASS][5];
+#pragma unroll
+          for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              const int row = pass * 64 + rsub, c = k * 8 + l;
+              rall[pass][k].u = make_uint4(0, 0, 0, 0);
+              if (has_res && row < BM && cm0 + row < p.M && c < nchunks)
+                rall[pass][k].u = *(const uint4*)(p.res + (size_t)(cm0 + row) * p.ldr + c * 8);
+            }
+#pragma unroll
+          for (int pass = 0; pass < NPASS; ++pass) {
+            const int row = pass * 64 + rsub, m = cm0 + row;
+            const bool live = row < BM && m < p.M;
+            Pack16 hh[5];
+            Pack16 (&rr)[5] = rall[pass];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              const int c = k * 8 + l;
+              hh[k].u = make_uint4(0, 0, 0, 0);
+              if (live && c < nchunks) hh[k].u = *(const uint4*)(smem + row * RS + c * 16);
+            }
+            float v[5][8];
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              const int c = k * 8 + l;
+              Pack16 o;
+              f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;   // the affine vectors are re-read per pass (L1 hits): held across
+              if (p.epi & RCDM_EPI_BIAS) {                 // the passes they cost 120 registers and spilled
+                const int cc = min(c, nchunks - 1);
+                a0 = *(const f32x4*)(p.bias + cc * 8);
+                a1 = *(const f32x4*)(p.bias + cc * 8 + 4);
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                o.e[e] = (f16)(((float)hh[k].e[e] + (e < 4 ? a0[e & 3] : a1[e & 3]) + (float)rr[k].e[e]) * sc);
+                v[k][e] = (live && c < nchunks) ? (float)o.e[e] : 0.f;
+                sum += v[k][e];
+              }
+              if (live && c < nchunks) {
+                epi_store16(p.out + (size_t)m * p.ldc + c * 8, o.u);
+                if (p.dup) epi_store16(p.out + (size_t)m * p.ldc + c * 8 + p.dup, o.u);
+              }
+            }
+            const float mean = group_sum<8>(sum) * invN;
+            float sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+              if (k * 8 + l < nchunks) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  v[k][e] -= mean;
+                  sq += v[k][e] * v[k][e];
+                }
+              }
+            const float rstd = rsqrtf(group_sum<8>(sq) * invN + p.ln_eps);
+            if (live) {
+              const float* pe_row = p.ln_pe ? p.ln_pe + (size_t)((m / p.ln_rpf) % p.ln_frames) * p.N : nullptr;
+#pragma unroll
+              for (int k = 0; k < 5; ++k) {
+                const int c = k * 8 + l;
+                if (c < nchunks) {
+                  f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+                  if (pe_row) {
+                    p0 = *(const f32x4*)(pe_row + c * 8);
+                    p1 = *(const f32x4*)(pe_row + c * 8 + 4);
+                  }
+                  const f32x4 g0 = *(const f32x4*)(p.ln_g + c * 8), g1 = *(const f32x4*)(p.ln_g + c * 8 + 4);
+                  const f32x4 b0 = *(const f32x4*)(p.ln_b + c * 8), b1 = *(const f32x4*)(p.ln_b + c * 8 + 4);
+                  Pack16 y;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    y.e[e] = (f16)(v[k][e] * rstd * g0[e] + (b0[e] + p0[e]));
+                    y.e[4 + e] = (f16)(v[k][4 + e] * rstd * g1[e] + (b1[e] + p1[e]));
+                  }
+                  epi_store16(p.ln_out + (size_t)m * p.ln_ld + c * 8, y.u);
+                }
+              }
+            }
+          }
+          return;
+        }
+      }
       if (p.epi == 0 && sc == 1.0f) {
         // plain projection (fused q/k/v): the staged halfs are the result; no conversion round trip
         for (int base = 0; base < ITEMS; base += NT * U) {

@@ -427,21 +427,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: no LDS crossbar) instead of six ds_bpermute round trips: the
 // wave-per-row kernel spent its life in those dependent shuffles (3.65 TB/s where a plain copy of the same bytes runs at
 // 6.2 TB/s on this part).
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-  v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f32<0x141>(v);  // row_half_mirror: quads are uniform by now, so the mirrored partner is the other quad's sum
-  if constexpr (LPR >= 16) v += dpp_f32<0x140>(v);  // row_mirror: the other 8-lane group of the 16-lane row
-  if constexpr (LPR >= 32) v += __shfl_xor(v, 16, 64);
-  if constexpr (LPR >= 64) v += __shfl_xor(v, 32, 64);
-  return v;
-}
-
 template <int LPR, int CPL, bool EARLY>
 __global__ __launch_bounds__(256) void layernorm_grp_kernel(const f16* __restrict__ x, f16* __restrict__ y,
                                                             const float* __restrict__ gamma,

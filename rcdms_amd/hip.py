@@ -25,6 +25,11 @@ class GemmDesc(C.Structure):
                 ("out_scale", C.c_float), ("split_k", C.c_int32), ("dup_rows", C.c_int32)]
 
 
+class LnFuse(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("pe", C.c_void_p), ("out", C.c_void_p), ("ld", C.c_int32),
+                ("rows_per_frame", C.c_int32), ("frames", C.c_int32), ("eps", C.c_float)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("n_img", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
                 ("c_in", C.c_int32), ("c_out", C.c_int32), ("stride", C.c_int32),
@@ -63,6 +68,7 @@ SYMBOLS = {
     "rcdm_version": (C.c_int, []),
     "rcdm_last_hip_error": (C.c_int, []),
     "rcdm_last_hip_error_string": (C.c_char_p, []),
+    "rcdm_gemm_ln": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(LnFuse), _P, _P, _P, _P, _P, _P]),
     "rcdm_gemm_workspace_bytes": (_SZ, [C.POINTER(GemmDesc)]),
     "rcdm_set_igemm_variant": (C.c_int, [_I]),
     "rcdm_set_igemm_pingpong": (C.c_int, [_I]),
@@ -199,6 +205,11 @@ def layernorm(desc, x, gamma, beta, pe, y, stream=None):
 def softmax_rows(M, N, ldx, ldy, scale, x, y, stream=None):
     _check(load().rcdm_softmax_rows(M, N, ldx, ldy, scale, x, y, stream_ptr() if stream is None else stream),
            "rcdm_softmax_rows")
+
+
+def gemm_ln(desc, ln, a, w, bias, residual, out, stream=None):
+    _check(load().rcdm_gemm_ln(C.byref(desc), C.byref(ln), a, w, bias, residual, out,
+                               stream_ptr() if stream is None else stream), "rcdm_gemm_ln")
 
 
 def flash_attn(desc, q, k, v, out, stream=None):

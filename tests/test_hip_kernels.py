@@ -154,6 +154,76 @@ def test_gemm_pingpong(hiplib, M, N, K, epi, split, variant):
     assert torch.isnan(out[:, N:].float()).all(), "wrote outside the N columns"
 
 
+@pytest.mark.parametrize("M,N,K,epi,pe,dup", [
+    (40960, 320, 320, 1 | 4, False, 0),     # to_out + residual -> norm2 / norm3 at the 64x64 level
+    (20480, 320, 320, 1, True, 20480),      # proj_in -> temporal norm with the positional encoding; shared-prefix dup
+    (4100, 320, 1280, 1 | 4, False, 0),     # ragged last tile, long K
+    (330, 64, 64, 1 | 4, True, 0),          # tiny-config width: masked chunks in every row group
+    (97, 200, 72, 0, False, 0),             # no bias, no residual, 25 chunks per row
+])
+def test_gemm_ln(hiplib, M, N, K, epi, pe, dup):
+    """rcdm_gemm_ln (the LayerNorm of the output rows fused into the 160x320 ping-pong tile's epilogue) against the fp32
+    reference, and bit for bit against the two calls it replaces: the same kernel without the LayerNorm + rcdm_layernorm."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(77 + M + N + K)
+    A = h16(torch.randn(M, K, generator=g))
+    W = h16(torch.randn(N, K, generator=g) * K ** -0.5)
+    bias = torch.randn(N, generator=g)
+    res = h16(torch.randn(M, N, generator=g) * 2 + 0.5)
+    gamma, beta = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    frames, rpf = 5, 64
+    table = O.sinusoid_table(N, frames)
+    x_ref = A @ W.t()
+    if epi & 1:
+        x_ref = x_ref + bias
+    if epi & 4:
+        x_ref = x_ref + res
+    y_ref = F.layer_norm(h16(x_ref), (N,), gamma, beta, 1e-5)
+    if pe:
+        y_ref = y_ref + table[(torch.arange(M) // rpf) % frames]
+    Ad, Wd, Rd = A.half().to(DEV), W.half().to(DEV), res.half().to(DEV)
+    bd, gd, btd, td = bias.to(DEV), gamma.to(DEV), beta.to(DEV), table.to(DEV)
+    rows = M + (dup if dup else 0)
+    out = torch.full((rows, N + 8), float("nan"), dtype=torch.float16, device=DEV)
+    y = torch.full((M, N + 8), float("nan"), dtype=torch.float16, device=DEV)
+    d = hip.GemmDesc(M, N, K, K, N + 8, N, epi, 1, 0, 1.0, 1, dup)
+    ln = hip.LnFuse(gd.data_ptr(), btd.data_ptr(), td.data_ptr() if pe else 0, y.data_ptr(), N + 8, rpf, frames, 1e-5)
+    for _ in range(2):
+        hip.gemm_ln(d, ln, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), Rd.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    close(out[:M, :N], x_ref)
+    close(y[:, :N], y_ref)
+    assert torch.isnan(out[:, N:].float()).all() and torch.isnan(y[:, N:].float()).all(), "wrote outside the N columns"
+    if dup:
+        assert torch.equal(out[dup:dup + M, :N], out[:M, :N])
+    # the unfused pair: same GEMM kernel (variant 6 = the 160x320 ping-pong tile), then rcdm_layernorm on its output
+    hip.set_igemm_variant(6)
+    out2 = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    y2 = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    d2 = hip.GemmDesc(M, N, K, K, N, N, epi, 1, 0, 1.0, 1, 0)
+    w = ws(hip.gemm_workspace_bytes(d2))
+    hip.gemm(d2, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), 0, Rd.data_ptr(), out2.data_ptr(), w.data_ptr(), w.numel())
+    hip.set_igemm_variant(-1)
+    hip.layernorm(hip.LayerNormDesc(M, N, N, N, 1e-5, rpf, frames), out2.data_ptr(), gd.data_ptr(), btd.data_ptr(),
+                  td.data_ptr() if pe else 0, y2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out[:M, :N], out2), "fused GEMM output differs from the unfused kernel's"
+    dy = (y[:, :N].float() - y2.float()).abs().max().item()
+    assert dy <= 2e-3 * y_ref.abs().max().item(), dy          # same inputs, another summation order in the row statistics
+
+
+def test_gemm_ln_rejects(hiplib):
+    from rcdms_amd import hip
+    x = torch.zeros(1 << 16, dtype=torch.float16, device=DEV)
+    f = torch.zeros(1 << 12, dtype=torch.float32, device=DEV)
+    ln = hip.LnFuse(f.data_ptr(), f.data_ptr(), 0, x.data_ptr(), 640, 1, 1, 1e-5)
+    for desc in (hip.GemmDesc(64, 640, 64, 64, 640, 640, 1, 1, 0, 1.0, 1, 0),        # row wider than one tile
+                 hip.GemmDesc(64, 320, 64, 64, 160, 160, 1 | 8, 1, 0, 1.0, 1, 0),    # GEGLU
+                 hip.GemmDesc(64, 320, 64, 64, 320, 320, 1, 1, 0, 1.0, 2, 0)):       # split-K
+        with pytest.raises(hip.RcdmError, match="RCDM_ESHAPE"):
+            hip.gemm_ln(desc, ln, x.data_ptr(), x.data_ptr(), f.data_ptr(), 0, x.data_ptr())
+
+
 @pytest.mark.parametrize("variant", [1, 2, 5, 6, 8, 9])
 @pytest.mark.parametrize("split", [1, 2])
 def test_gemm_dup_rows(hiplib, variant, split):

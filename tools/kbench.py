@@ -94,6 +94,22 @@ def bench_gemm(variants, rounds):
                                   ws.data_ptr(), ws.numel())
             med, mn = timeit(fn, rounds)
             line += f" v{v}: {med:7.1f}us {2.0 * M * N * K / med / 1e6:6.0f}TF |"
+        if N <= 320 and not (epi & (8 | 16 | 2)):   # the LayerNorm that follows, fused (rcdm_gemm_ln) vs as its own launch
+            gam, bet = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+            y = torch.empty(M, N, device=DEV, dtype=torch.float16)
+            d1 = hip.GemmDesc(M, N, K, K, N, N, epi, 1, 0, 1.0, 1, 0)
+            ln = hip.LnFuse(gam.data_ptr(), bet.data_ptr(), 0, y.data_ptr(), N, 1, 1, 1e-5)
+            lnd = hip.LayerNormDesc(M, N, N, N, 1e-5, 1, 1)
+            ws1 = torch.empty(16, dtype=torch.uint8, device=DEV)
+            hip.set_igemm_variant(-1)
+
+            def pair():
+                hip.gemm(d1, A.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, res.data_ptr(), out.data_ptr(), ws1.data_ptr(), 16)
+                hip.layernorm(lnd, out.data_ptr(), gam.data_ptr(), bet.data_ptr(), 0, y.data_ptr())
+            t_pair, _ = timeit(pair, rounds)
+            t_fused, _ = timeit(lambda: hip.gemm_ln(d1, ln, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(),
+                                                    out.data_ptr()), rounds)
+            line += f" gemm + layernorm {t_pair:6.1f}us, rcdm_gemm_ln {t_fused:6.1f}us |"
         print(line, flush=True)
     hip.set_igemm_variant(-1)
     hip.set_igemm_pingpong(True)
