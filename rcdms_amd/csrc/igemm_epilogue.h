@@ -98,29 +98,29 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
       constexpr int CPR = BN / 8;
       constexpr int ITEMS = BM * CPR;
       const bool has_res = (p.epi & RCDM_EPI_RESIDUAL) != 0;
-      if constexpr (LN_OK && BN >= 320 && NT == 512) {
+      if constexpr (LN_OK && BN >= 320) {
         if (p.epi & kEpiLN) {
           // ---- rcdm_gemm_ln: the tile spans the whole output row (N <= BN).  Eight lanes share a row (five 16-byte chunks
-          // each, c = 8 k + l), 64 rows per pass: out = f16((acc + bias + residual) * scale) is stored, and the LayerNorm
+          // each, c = 8 k + l), NT / 8 rows per pass: out = f16((acc + bias + residual) * scale) is stored, and the LayerNorm
           // of exactly those rounded values — mean, then squared deviations, two DPP group sums — goes to ln_out.  Same
           // arithmetic as layernorm_grp_kernel<8, 5> reading `out` back.
           const int l = t & 7, rsub = t >> 3, nchunks = p.N >> 3;
           const float invN = 1.0f / (float)p.N;
           // the residual tile of ALL passes is requested first: one HBM round trip for the block instead of one per pass
-          constexpr int NPASS = (BM + 63) / 64;
+          constexpr int RPP = NT / 8, NPASS = (BM + RPP - 1) / RPP;
           Pack16 rall[NPASS][5];
 #pragma unroll
           for (int pass = 0; pass < NPASS; ++pass)
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-              const int row = pass * 64 + rsub, c = k * 8 + l;
+              const int row = pass * RPP + rsub, c = k * 8 + l;
               rall[pass][k].u = make_uint4(0, 0, 0, 0);
               if (has_res && row < BM && cm0 + row < p.M && c < nchunks)
                 rall[pass][k].u = *(const uint4*)(p.res + (size_t)(cm0 + row) * p.ldr + c * 8);
             }
 #pragma unroll
           for (int pass = 0; pass < NPASS; ++pass) {
-            const int row = pass * 64 + rsub, m = cm0 + row;
+            const int row = pass * RPP + rsub, m = cm0 + row;
             const bool live = row < BM && m < p.M;
             Pack16 hh[5];
             Pack16 (&rr)[5] = rall[pass];
