@@ -147,3 +147,69 @@ def test_flash_random_shapes(hiplib):
             close(out.reshape(batch, Lq, C), ref)
         except AssertionError as e:
             raise AssertionError(f"case {case}: B={batch} H={heads} Lq={Lq} Lk={Lk} d={d} causal={causal} pad={pad}: {e}")
+
+
+def test_xattn_random_shapes(hiplib):
+    """rcdm_xattn_pack_kv + rcdm_xattn: any head dim the flash kernel takes, 1..96 keys, ragged query counts, K and V in
+    separate buffers with padded leading dimensions."""
+    from rcdms_amd import hip
+    rnd = random.Random(4242)
+    for case in range(24):
+        batch, heads = rnd.choice([1, 2, 5]), rnd.choice([1, 2, 3, 8])
+        d = 8 * rnd.randint(1, 20)
+        Lq, Lk = rnd.randint(1, 700), rnd.randint(1, 96)
+        g = torch.Generator().manual_seed(900 + case)
+        C = heads * d
+        q = h16(torch.randn(batch, Lq, C, generator=g))
+        k = h16(torch.randn(batch, Lk, C, generator=g) * 1.5)
+        v = h16(torch.randn(batch, Lk, C, generator=g))
+        ref = O.attention_core(q, k, v, heads)
+        ldq, ldk, ldv, ldo = (C + 8 * rnd.randint(0, 3) for _ in range(4))
+
+        def padded(t, rows, ld):
+            buf = torch.zeros(rows, ld, dtype=torch.float16)
+            buf[:, :C] = t.reshape(rows, C).half()
+            return buf.to(DEV)
+        qd, kd, vd = padded(q, batch * Lq, ldq), padded(k, batch * Lk, ldk), padded(v, batch * Lk, ldv)
+        img = torch.empty(hip.xattn_image_bytes(batch, heads, d), dtype=torch.uint8, device=DEV)
+        out = torch.full((batch * Lq, ldo), float("nan"), dtype=torch.float16, device=DEV)
+        desc = hip.AttnDesc(batch, heads, Lq, Lk, d, ldq, ldk, ldv, ldo, d ** -0.5)
+        hip.xattn_pack_kv(kd.data_ptr(), vd.data_ptr(), batch, Lk, heads, d, ldk, ldv, img.data_ptr())
+        hip.xattn(desc, qd.data_ptr(), img.data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        try:
+            close(out[:, :C].reshape(batch, Lq, C), ref)
+            assert torch.isnan(out[:, C:].float()).all(), "wrote outside the C columns"
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: B={batch} H={heads} Lq={Lq} Lk={Lk} d={d}: {e}")
+
+
+def test_layernorm_random_shapes(hiplib):
+    """rcdm_layernorm (row-group kernel: every lanes-per-row / chunks-per-lane combination, masked chunks, ragged last
+    wave), with and without the positional-encoding table, padded leading dimensions."""
+    from rcdms_amd import hip
+    rnd = random.Random(99)
+    for case in range(30):
+        M = rnd.choice([1, 3, 31, 64, 257, 1000, 4099])
+        C = 8 * rnd.randint(1, 256)
+        pe = rnd.random() < 0.4
+        frames, rpf = rnd.choice([1, 5, 8]), rnd.choice([1, 7, 64])
+        g = torch.Generator().manual_seed(300 + case)
+        x = h16(torch.randn(M, C, generator=g) * 2 + 0.3)
+        gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        table = torch.randn(frames, C, generator=g)
+        ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+        if pe:
+            ref = ref + table[(torch.arange(M) // rpf) % frames]
+        ldx, ldy = C + 8 * rnd.randint(0, 2), C + 8 * rnd.randint(0, 2)
+        xd = torch.zeros(M, ldx, dtype=torch.float16); xd[:, :C] = x.half(); xd = xd.to(DEV)
+        y = torch.full((M, ldy), float("nan"), dtype=torch.float16, device=DEV)
+        gd, bd, td = gamma.to(DEV), beta.to(DEV), table.to(DEV)
+        d = hip.LayerNormDesc(M, C, ldx, ldy, 1e-5, rpf, frames)
+        hip.layernorm(d, xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), td.data_ptr() if pe else 0, y.data_ptr())
+        torch.cuda.synchronize()
+        try:
+            close(y[:, :C], ref)
+            assert torch.isnan(y[:, C:].float()).all(), "wrote outside the C columns"
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: M={M} C={C} pe={pe} frames={frames} rpf={rpf}: {e}")
