@@ -17,6 +17,7 @@ stored for both (0.21 of the 11.044 TFLOP; exact — config.shared_cfg_prefix, -
 still prices the reference's full 11.044 TFLOP per call.  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
 timed on this box's host cores on a bounded sample (a few UNet calls of the 50), extrapolated to T calls."""
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -97,6 +98,21 @@ def cpu_baseline(model, latent, ctx_len, ddim_steps, budget_s=25.0):
     fps = 5.0 / (ddim_steps * t_call)
     return {"value": fps, "unit": "story-frames/s", "cores": threads, "kind": "port",
             "sample": how + f"; b=2 f=5 L={ctx_len}, fp32 torch CPU restatement, extrapolated x{ddim_steps} steps"}
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner on the process's stdout (fd 1) when its first communicator comes up; the contract is
+    ONE JSON line there, so fd 1 points at stderr while communicators are created and first used."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def parse_args(argv=None):
@@ -229,7 +245,9 @@ def main(argv=None):
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()      # brings the RCCL communicator up here, banner and all
 
     import __graft_entry__
     if local_rank == 0:
@@ -251,10 +269,12 @@ def main(argv=None):
     if a.cfg_split:
         from rcdms_amd.dist import CfgSplit
         if world == 1:
-            comm = hip.Comm(hip.Comm.unique_id(), 1, 0)
+            with stdout_to_stderr():
+                comm = hip.Comm(hip.Comm.unique_id(), 1, 0)
             split = CfgSplit(0, lambda send, recv, n: comm.allgather(send, recv, n))
         else:
-            split, units = CfgSplit.from_world(), world // 2
+            with stdout_to_stderr():
+                split, units = CfgSplit.from_world(), world // 2
             story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42 + rank // 2)
     loop = DenoiseLoop(model, S, 5, a.latent, a.latent, a.ctx_len, a.guidance, sched, T,
                        share_cfg_prefix=not a.no_share_prefix, cfg_split=split)
