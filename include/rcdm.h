@@ -219,6 +219,31 @@ typedef struct {
 int rcdm_temporal_attn(const rcdm_temporal_attn_desc* d, const void* qkv, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused feed-forward, row-stationary (rowff.hip):  out[m][:] = x[m][:] + FF_geglu(LayerNorm(x[m][:]))  in one launch.
+ *   replaces the chain nn.LayerNorm -> diffusers FeedForward(dim, activation_fn="geglu") -> + hidden_states at
+ *   attention.py:514 (norm3 / ff of BasicTransformerBlock.forward) and motion_module.py:243 (ff_norm / ff of
+ *   TemporalTransformerBlock.forward): Linear(C -> 8C) -> split (hidden, gate) -> hidden * gelu(gate) (exact erf
+ *   GELU) -> Linear(4C -> C) -> + bias -> + x.  The 4C-wide hidden tensor is never written: a wave keeps its 16 token
+ *   rows and their fp32 output accumulator in registers and streams the weights through LDS.
+ *   Weights come as the fragment-major stream rcdm_pack_ff_stream writes once (12 C^2 halfs, rcdm_ff_stream_bytes):
+ *   w1 = ff.net.0.proj.weight fp32 [8C][C], b1 = ff.net.0.proj.bias [8C], w2 = ff.net.2.weight fp32 [C][4C];
+ *   b1_packed [8C] floats.  b2 = ff.net.2.bias [C].  out may alias x.  Supported C: rcdm_ff_fused_supported.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t M, C;
+  int32_t ldx, ldo;   /* row strides in elements, multiples of 8 */
+  float eps;          /* LayerNorm eps (1e-5) */
+} rcdm_ff_desc;
+size_t rcdm_ff_stream_bytes(int32_t C);
+int rcdm_ff_fused_supported(int32_t C);
+/* tuning / test knob: -1 = automatic (default), 0 = ten waves of 16 rows per block, 1 = four waves of 48 rows */
+int rcdm_set_ff_variant(int32_t variant);
+int rcdm_pack_ff_stream(const float* w1, const float* b1, const float* w2, int32_t C, void* wstream, float* b1_packed,
+                        void* stream);
+int rcdm_ff_fused(const rcdm_ff_desc* d, const void* x, const float* ln_gamma, const float* ln_beta, const void* wstream,
+                  const float* b1_packed, const float* b2, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Row softmax: y[m][n] = softmax over n of (scale * x[m][n]); f16 rows, fp32 math, N % 8 == 0, N <= 4096, scale > 0.
  *   With two rcdm_gemm calls (scores = Q K^T, out = P V^T^T) it is the attention of heads too wide for
  *   rcdm_flash_attn: the single 512-channel head of the SD-1.5 VAE mid block (diffusers 0.24.0 AutoencoderKL,

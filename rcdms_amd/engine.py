@@ -309,6 +309,18 @@ class Packer:
         self._tmp += [w, b]
         return wd, bd
 
+    def ff_stream(self, w1key, b1key, w2key):
+        """(weight stream, packed b1) for rcdm_ff_fused, or None when the library has no fused kernel for this width."""
+        w1, b1, w2 = self.f32(w1key), self.f32(b1key), self.f32(w2key)
+        Cc = w2.shape[0]
+        if not (FF_FUSE and w1.shape == (8 * Cc, Cc) and w2.shape == (Cc, 4 * Cc) and hip.ff_fused_supported(Cc)):
+            return None
+        ws = torch.empty(hip.ff_stream_bytes(Cc), dtype=torch.uint8, device=self.device)
+        b1p = torch.empty(8 * Cc, dtype=torch.float32, device=self.device)
+        hip.pack_ff_stream(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), Cc, ws.data_ptr(), b1p.data_ptr())
+        self._tmp += [w1, b1, w2]
+        return ws, b1p
+
     def done(self):
         torch.cuda.synchronize(self.device)
         self._tmp.clear()
@@ -360,8 +372,10 @@ def pack_basic_block(pk, b):
         w.q2, w.q2_b, w.kv2, w.kv2_b, w.o2, w.o2_b = a2.q, a2.q_b, a2.kv, a2.kv_b, a2.o, a2.o_b
         w.ctx_dim = pk.sd[b + "attn2.to_k.weight"].shape[1]
     w.geglu = pk.has(b + "ff.net.0.proj.weight") and pk.sd[b + "ff.net.0.proj.weight"].shape[0] == 8 * C
+    w.ff_stream = None
     if w.geglu:
         w.ff1, w.ff1_b = pk.geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias")
+        w.ff_stream = pk.ff_stream(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight")
     else:
         w.ff1, w.ff1_b = pk.mat_f16(b + "ff.net.0.proj.weight"), pk.vec(b + "ff.net.0.proj.bias")
     w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
@@ -397,6 +411,7 @@ def pack_motion(pk, p, n_attn):
     w.ff_ln = (pk.vec(b + "ff_norm.weight"), pk.vec(b + "ff_norm.bias"))
     w.ff1, w.ff1_b = pk.geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias")
     w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
+    w.ff_stream = pk.ff_stream(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight")
     return w
 
 
@@ -432,8 +447,25 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
                  dup_rows=dup_rows)
 
 
-def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C):
-    """x += FeedForward_geglu(LayerNorm(x))  (attention.py:514 / motion_module.py:243), in place on tok."""
+# rcdm_ff_fused (rowff.hip): LayerNorm -> GEGLU feed-forward -> + residual as ONE row-stationary launch, for the channel
+# counts the library has a kernel for.  RCDM_FF_FUSE=0 keeps the three-launch chain (same-process A/B).
+FF_FUSE = os.environ.get("RCDM_FF_FUSE", "1") != "0"
+
+
+def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None):
+    """x += FeedForward_geglu(LayerNorm(x))  (attention.py:514 / motion_module.py:243), in place on tok.
+    stream: (fragment-major weight stream, packed b1) of Packer.ff_stream, or None for the unfused chain."""
+    if stream is not None:
+        ws, b1p = stream
+        d = hip.FFDesc(M, C, tok.ld, tok.ld, 1e-5)
+
+        def op():
+            hip.ff_fused(d, tok.ptr, ln_g.data_ptr(), ln_b.data_ptr(), ws.data_ptr(), b1p.data_ptr(), ff2_b.data_ptr(), tok.ptr)
+        plan.add(op, f"ff_fused M={M} C={C}")
+        plan.keep += [ln_g, ln_b, ws, b1p, ff2_b]
+        plan.n_launch += 1
+        plan.last_gemm = None
+        return
     emit_layernorm(plan, tok, ln_g, ln_b, a)
     gg = plan.rows("geglu", M, 4 * C)
     emit_gemm(plan, a, ff1, 8 * C, C, gg, bias=ff1_b, geglu=True)
@@ -469,7 +501,7 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
             emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), n_seq, heads, Lq, L, d_head, ao)
         emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok)
     if w.geglu:
-        emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, M, C)
+        emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, M, C, stream=w.ff_stream)
     else:   # FeedForward("gelu"): Linear -> exact GELU -> Linear (stage-1 prior blocks)
         emit_layernorm(plan, tok, w.ln[2][0], w.ln[2][1], a)
         hid = plan.rows("geglu", M, 4 * C)
@@ -520,7 +552,7 @@ def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
         ao = plan.rows("attn_out", g.M, C)
         emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)
         emit_gemm(plan, ao, at.o, C, C, tok, bias=at.o_b, residual=tok)
-    emit_ff(plan, tok, w.ff_ln[0], w.ff_ln[1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, g.M, C)
+    emit_ff(plan, tok, w.ff_ln[0], w.ff_ln[1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, g.M, C, stream=w.ff_stream)
     emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
 
 

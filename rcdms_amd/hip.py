@@ -50,6 +50,10 @@ class LayerNormDesc(C.Structure):
                 ("eps", C.c_float), ("rows_per_frame", C.c_int32), ("frames", C.c_int32)]
 
 
+class FFDesc(C.Structure):
+    _fields_ = [("M", C.c_int32), ("C", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32), ("eps", C.c_float)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("heads", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
                 ("d", C.c_int32), ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32),
@@ -84,6 +88,11 @@ SYMBOLS = {
     "rcdm_flash_attn": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
     "rcdm_flash_attn_masked": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _I, _P, _P]),
     "rcdm_temporal_attn": (C.c_int, [C.POINTER(TemporalAttnDesc), _P, _P, _P]),
+    "rcdm_ff_stream_bytes": (_SZ, [_I]),
+    "rcdm_ff_fused_supported": (C.c_int, [_I]),
+    "rcdm_set_ff_variant": (C.c_int, [_I]),
+    "rcdm_pack_ff_stream": (C.c_int, [_P, _P, _P, _I, _P, _P, _P]),
+    "rcdm_ff_fused": (C.c_int, [C.POINTER(FFDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "rcdm_timestep_embed": (C.c_int, [_P, _I, _I, _P, _P]),
     "rcdm_small_linear": (C.c_int, [_P, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "rcdm_assemble_input": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -225,6 +234,28 @@ def flash_attn_masked(desc, q, k, v, key_valid, causal, out, stream=None):
 def temporal_attn(desc, qkv, out, stream=None):
     _check(load().rcdm_temporal_attn(C.byref(desc), qkv, out,
                                      stream_ptr() if stream is None else stream), "rcdm_temporal_attn")
+
+
+def ff_stream_bytes(Cc):
+    return load().rcdm_ff_stream_bytes(Cc)
+
+
+def ff_fused_supported(Cc):
+    return bool(load().rcdm_ff_fused_supported(Cc))
+
+
+def set_ff_variant(v):
+    _check(load().rcdm_set_ff_variant(v), "rcdm_set_ff_variant")
+
+
+def pack_ff_stream(w1, b1, w2, Cc, wstream, b1p, stream=None):
+    _check(load().rcdm_pack_ff_stream(w1, b1, w2, Cc, wstream, b1p, stream_ptr() if stream is None else stream),
+           "rcdm_pack_ff_stream")
+
+
+def ff_fused(desc, x, ln_g, ln_b, wstream, b1p, b2, out, stream=None):
+    _check(load().rcdm_ff_fused(C.byref(desc), x, ln_g, ln_b, wstream, b1p, b2, out,
+                                stream_ptr() if stream is None else stream), "rcdm_ff_fused")
 
 
 def timestep_embed(t, rows, dim, out, stream=None):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of single librcdm_hip kernels at the UNet's hot shapes (HIP-event timed, interleaved rounds).
-usage: python tools/kbench.py [gemm|conv|attn|norm|all] [--variants 0,1,2] [--rounds 5]"""
+usage: python tools/kbench.py [gemm|conv|attn|norm|ff|all] [--variants 0,1,2] [--rounds 5]"""
 import argparse
 import os
 import sys
@@ -209,6 +209,51 @@ def bench_norm(rounds, only=""):
         print(f"norm {name:28s} {by / 1e6:8.1f} MB | {med:7.1f}us {by / med / 1e6:6.2f}TB/s (2 reads + 1 write)", flush=True)
 
 
+def bench_ff(rounds, only=""):
+    """LayerNorm -> GEGLU feed-forward -> + residual: the three-launch chain vs the row-stationary fused kernel."""
+    for name, M, C in [("L0 FF C=320", 40960, 320), ("L0 FF C=320 half", 20480, 320), ("L1 FF C=640", 10240, 640),
+                       ("L2 FF C=1280", 2560, 1280)]:
+        if only and only not in name:
+            continue
+        x = torch.randn(M, C, device=DEV).half()
+        g, b = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+        w1 = torch.randn(8 * C, C, device=DEV) * C ** -0.5
+        b1 = torch.randn(8 * C, device=DEV)
+        w2 = torch.randn(C, 4 * C, device=DEV) * (4 * C) ** -0.5
+        b2 = torch.randn(C, device=DEV)
+        a = torch.empty_like(x)
+        hid = torch.empty(M, 4 * C, device=DEV, dtype=torch.float16)
+        y = torch.empty_like(x)
+        wp = torch.empty(8 * C, C, dtype=torch.float16, device=DEV)
+        bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+        hip.pack_geglu_rows(w1.data_ptr(), b1.data_ptr(), 8 * C, C, wp.data_ptr(), bp.data_ptr())
+        w2h = w2.half().contiguous()
+        lnd = hip.LayerNormDesc(M, C, C, C, 1e-5, 1, 1)
+        d1 = hip.GemmDesc(M, 8 * C, C, C, 4 * C, 0, 9, 1, 0, 1.0, 0)
+        d2 = hip.GemmDesc(M, C, 4 * C, 4 * C, C, C, 5, 1, 0, 1.0, 0)
+        ws = torch.empty(max(hip.gemm_workspace_bytes(d1), hip.gemm_workspace_bytes(d2), 16), dtype=torch.uint8, device=DEV)
+
+        def chain():
+            hip.layernorm(lnd, x.data_ptr(), g.data_ptr(), b.data_ptr(), 0, a.data_ptr())
+            hip.gemm(d1, a.data_ptr(), wp.data_ptr(), bp.data_ptr(), 0, 0, hid.data_ptr(), ws.data_ptr(), ws.numel())
+            hip.gemm(d2, hid.data_ptr(), w2h.data_ptr(), b2.data_ptr(), 0, x.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel())
+        fl = 2.0 * M * 12 * C * C
+        med, mn = timeit(chain, rounds)
+        line = f"ff   {name:28s} {fl / 1e9:8.1f} GF | chain {med:7.1f}us {fl / med / 1e6:6.0f}TF"
+        if hip.ff_fused_supported(C):
+            wsr = torch.empty(hip.ff_stream_bytes(C), dtype=torch.uint8, device=DEV)
+            b1p = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+            hip.pack_ff_stream(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), C, wsr.data_ptr(), b1p.data_ptr())
+            fd = hip.FFDesc(M, C, C, C, 1e-5)
+            for fv in (0, 1):
+                hip.set_ff_variant(fv)
+                med2, mn2 = timeit(lambda: hip.ff_fused(fd, x.data_ptr(), g.data_ptr(), b.data_ptr(), wsr.data_ptr(), b1p.data_ptr(),
+                                                        b2.data_ptr(), y.data_ptr()), rounds)
+                line += f" | fused v{fv} {med2:7.1f}us (min {mn2:.1f}) {fl / med2 / 1e6:6.0f}TF"
+            hip.set_ff_variant(-1)
+        print(line, flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -230,3 +275,5 @@ if __name__ == "__main__":
         bench_attn(a.rounds, a.only)
     if a.what in ("norm", "all"):
         bench_norm(a.rounds, a.only)
+    if a.what in ("ff", "all"):
+        bench_ff(a.rounds, a.only)
