@@ -236,12 +236,42 @@ typedef struct {
 } rcdm_ff_desc;
 size_t rcdm_ff_stream_bytes(int32_t C);
 int rcdm_ff_fused_supported(int32_t C);
-/* tuning / test knob: -1 = automatic (default), 0 = ten waves of 16 rows per block, 1 = four waves of 48 rows */
-int rcdm_set_ff_variant(int32_t variant);
 int rcdm_pack_ff_stream(const float* w1, const float* b1, const float* w2, int32_t C, void* wstream, float* b1_packed,
                         void* stream);
 int rcdm_ff_fused(const rcdm_ff_desc* d, const void* x, const float* ln_gamma, const float* ln_beta, const void* wstream,
                   const float* b1_packed, const float* b2, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-stationary chain (rowff.hip), one launch:
+ *     tok[m][:] = a_in[m][:] W_a^T + a_bias (+ res[m][:])                  -> stored (f16 [M][ldt])
+ *     y[m][:]   = LayerNorm(tok[m][:]) * gamma + beta (+ pe[(m / rows_per_frame) % frames][:])
+ *     tail 1 / 3:  out[m][0 : tail*C] = y[m][:] W_t^T          (no bias; W_t = fp32 [tail*C][C], e.g. [to_q; to_k; to_v])
+ *     tail 0:      out[m][:] = tok[m][:] + FF_geglu(y[m][:])   (as rcdm_ff_fused; may be written in place of tok)
+ *   replaces, in BasicTransformerBlock.forward / Transformer3DModel.forward (attention.py:330,479-514) and
+ *   TemporalTransformer3DModel / TemporalTransformerBlock.forward (motion_module.py:166,234-243,299-302):
+ *     proj_in -> norm1 -> [to_q | to_k | to_v]                         (res = NULL, tail 3)
+ *     attn1.to_out[0] + hidden_states -> norm2 -> attn2.to_q           (res = tok, tail 1)
+ *     attention_blocks[i].to_out[0] + hidden_states -> norms[i + 1] + pos_encoder -> [to_q | to_k | to_v]   (tail 3, pe)
+ *     attn2.to_out[0] / attention_blocks[-1].to_out[0] + hidden_states -> norm3 / ff_norm -> ff -> + hidden_states  (tail 0)
+ *   W_a = fp32 [C][C] (nn.Linear layout).  The weights come as one fragment-major stream (rcdm_pack_rowchain,
+ *   rcdm_rowchain_stream_bytes); b1_packed / b2 only with tail 0.  tok may alias res, out may alias tok (tail 0) — a block
+ *   reads and writes only its own rows.  Supported C: rcdm_rowchain_supported.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t M, C;
+  int32_t lda, ldr, ldt, ldo;      /* row strides in elements, multiples of 8 (ldr only with res) */
+  int32_t tail;                    /* 0 = feed-forward, 1 = GEMM to C columns, 3 = GEMM to 3C columns */
+  int32_t rows_per_frame, frames;  /* only with pe */
+  float eps;                       /* LayerNorm eps (1e-5) */
+} rcdm_rowchain_desc;
+int rcdm_rowchain_supported(int32_t C);
+size_t rcdm_rowchain_stream_bytes(int32_t C, int32_t tail);
+/* wa [C][C]; tail 1 / 3: wt [tail*C][C]; tail 0: w1 [8C][C], b1 [8C], w2 [C][4C] and b1_packed [8C] (out) */
+int rcdm_pack_rowchain(const float* wa, int32_t C, int32_t tail, const float* wt, const float* w1, const float* b1,
+                       const float* w2, void* wstream, float* b1_packed, void* stream);
+int rcdm_rowchain(const rcdm_rowchain_desc* d, const void* a_in, const void* res, void* tok, const float* a_bias,
+                  const float* ln_gamma, const float* ln_beta, const float* pe, const void* wstream, const float* b1_packed,
+                  const float* b2, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row softmax: y[m][n] = softmax over n of (scale * x[m][n]); f16 rows, fp32 math, N % 8 == 0, N <= 4096, scale > 0.

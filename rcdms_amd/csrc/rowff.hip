@@ -1,80 +1,98 @@
-// rowff.hip — ROW-STATIONARY fused feed-forward for gfx950:  out = x + FeedForward_geglu(LayerNorm(x))  in ONE launch.
-// Replaces the chain  nn.LayerNorm -> diffusers FeedForward(dim, activation_fn="geglu") -> + hidden_states  of
-// BasicTransformerBlock.forward (src/models/attention.py:514: norm3 -> ff -> +) and TemporalTransformerBlock.forward
-// (src/models/motion_module.py:243: ff_norm -> ff -> +), which the library otherwise runs as three launches
-// (rcdm_layernorm, rcdm_gemm with the GEGLU epilogue, rcdm_gemm with bias + residual) with the 4C-wide hidden tensor
-// written to and read back from HBM (105 MB per call at the 64x64 level of the 512x512 UNet).
+// rowff.hip — ROW-STATIONARY fused token-matrix chains for gfx950 (the C = 320 level of the 512x512 UNet).
+//
+//   rcdm_ff_fused :  out = x + FeedForward_geglu(LayerNorm(x))                                      (one launch)
+//   rcdm_rowchain :  tok = a W_a^T + b_a (+ res);  y = LayerNorm(tok) (+ pe);  then one of
+//                      out = y W_t^T                      (N = C: cross-attention query, N = 3C: fused q | k | v)
+//                      out = tok + FeedForward_geglu(y)   (y computed with the feed-forward's own LayerNorm)
+// Replace, per launch, the chains the library otherwise runs as 3-5 launches with every intermediate tensor in HBM:
+//   * nn.LayerNorm -> diffusers FeedForward(dim, activation_fn="geglu") -> + hidden_states
+//     (BasicTransformerBlock.forward src/models/attention.py:514, TemporalTransformerBlock.forward motion_module.py:243);
+//   * proj_in / to_out[0] (+ residual) -> norm1 / norm2 / norms[i] (+ PositionalEncoding) -> to_q | to_k | to_v
+//     (attention.py:330,482-499,121,139-141; motion_module.py:166,236-241,299-302);
+//   * to_out[0] + residual -> norm3 / ff_norm -> ff -> + residual (attention.py:164,514; motion_module.py:243).
 //
 // Decomposition (round 3): the implicit-GEMM kernels tile BOTH dimensions, so their operands
-// stream L2 -> LDS for every tile and every intermediate tensor round-trips HBM.  Here a WAVE owns 16 PF token rows for
-// the whole chain and only the weights move:
-//   * the wave's LayerNorm'ed rows live in registers as the B operands of v_mfma_f32_16x16x32_f16 (PF x C / 32
-//     fragments), loaded once;
-//   * the fp32 output accumulator of those rows lives in registers (PF x C / 16 fragments);
-//   * hidden units are processed in groups of 32: GEMM1 (K = C) for 16 hidden + 16 gate columns, twice, gives the GEGLU
-//     inputs in the MFMA accumulator layout, lane (pixel, kg) holding hidden units 4 kg .. 4 kg + 3 of each 16 — which
-//     IS the B-operand layout of the next MFMA if the k-slots of W2 are permuted to match (done once, in the weight
-//     pack): h = (a_h + b_h) * gelu(a_g + b_g) goes from accumulator registers straight into GEMM2 (K = 32,
-//     C / 16 MFMAs per 16 rows into the resident output accumulator).  The hidden tensor never exists, not even in LDS;
-//   * the only LDS traffic of the loop is the weight stream: W1 / W2 are packed FRAGMENT-MAJOR in consumption order
-//     (rcdm_pack_ff_stream: every MFMA A operand is one contiguous 1-KiB block in lane order), so a buffer_load ... lds
-//     piece is one fragment, LDS is written and read linearly (no swizzle, no bank conflicts), and the whole LDS is one
-//     ring of R chunks of 2 C / 32 fragments that all NW waves of the block consume in lock step (one s_barrier per
-//     chunk, counted vmcnt).  Weight bytes L2 -> LDS per block: 24 C^2 (2.4 MB at C = 320) for 16 PF NW rows.
-// Every wave reads every weight fragment from LDS once per PF MFMAs; with PF = 1 and ten waves per CU (the first version)
-// the LDS pipe was as loaded as the matrix pipe and the two did not overlap (measured: reads alone 1000 clocks per chunk,
-// MFMAs alone 1000, together 1500).  Hence PF = 3 on FOUR waves, one per SIMD, each with the whole 512-register file:
-// 192-row blocks, 0.4 x the LDS traffic per flop.
+// stream L2 -> LDS for every tile and every intermediate tensor round-trips HBM.  Here a WAVE owns 16 token rows for the
+// whole chain and only the weights move:
+//   * the wave's current activation rows live in registers as the B operands of v_mfma_f32_16x16x32_f16 (C / 32
+//     fragments: lane (row l15, kg) holds channels 32 s + 8 kg .. + 7 of k-step s: 40 VGPRs at C = 320);
+//   * a GEMM's fp32 accumulators land in the MFMA D layout, lane (row, kg) holding 4 output rows (channels) of each
+//     16-channel fragment.  The weight ROWS are permuted in the pack ("P layout": fragment i, D row 4 kg + e <-> channel
+//     32 (i >> 1) + 8 kg + 4 (i & 1) + e), so that fragments 2 s and 2 s + 1 together are exactly the B operand of
+//     k-step s of the NEXT GEMM: activations chain from accumulator registers into operands with no data movement,
+//     LayerNorm is a per-lane reduction + two cross-lane adds, and global loads / stores are 16 bytes per lane;
+//   * the feed-forward's hidden units are processed in groups of 32: GEMM1 (K = C) for 16 hidden + 16 gate columns,
+//     twice, gives the GEGLU inputs in the D layout, h = (a_h + b_h) * gelu(a_g + b_g) goes from accumulator registers
+//     straight into GEMM2 (K = 32, C / 16 MFMAs into the resident output accumulator): the 4C-wide hidden tensor never
+//     exists, not even in LDS;
+//   * the only LDS traffic of the loops is the weight stream: all weights of a chain are packed FRAGMENT-MAJOR in
+//     consumption order (rcdm_pack_*: every MFMA A operand is one contiguous 1-KiB block in lane order), so a
+//     buffer_load ... lds piece is one fragment, LDS is written and read linearly (no swizzle, no bank conflicts), and
+//     the whole LDS is one ring of R chunks of 20 fragments that all NW waves of the block consume in lock step (one
+//     s_barrier per chunk, counted vmcnt).
+// One LDS read per MFMA is the price (the activations cost none): at ten waves per CU the LDS pipe is as loaded as the
+// matrix pipe (measured, feed-forward: reads alone 1000 clocks per chunk, MFMAs alone 1000, together 1450).  The variant
+// with 48 rows per wave on four waves (one per SIMD, 512 registers, 0.4 x the LDS reads) was built and measured slower
+// (147 vs 118 us): a single wave issues one instruction per ~4 clocks, and MFMAs + GEGLU arithmetic + reads do not fit.
+//
+// Block = NW = 10 waves = 160 rows (the 40960 / 10240 / 2560 / 640 token rows of the UNet are an exact number of blocks;
+// 3 + 3 + 2 + 2 waves per SIMD at <= 168 registers).
 #include "common.h"
 #include "pp_sync.h"
 #include <type_traits>
 
-#ifndef RCDM_FF_PD
-#define RCDM_FF_PD 4   // fragment reads in flight ahead of the MFMAs that consume them
-#endif
 #ifndef RCDM_FF_ABLATE
 #define RCDM_FF_ABLATE 0  // debug builds (wrong results, timing only): 1 no DMA after the prefill, 2 no MFMA, 4 no fragment
 #endif                    // reads, 8 no barrier in the loop, 16 no epilogue, 32 no GEGLU arithmetic
 
 namespace {
 
-struct FFArgs {
-  const f16* x;        // [M][ldx]
-  f16* out;            // [M][ldo]  (may alias x: every block reads and writes only its own rows)
+enum { TAIL_FF = 0, TAIL_N1 = 1, TAIL_N3 = 3 };
+
+struct RowArgs {
+  const f16* a_in;     // [M][lda]: stage-A input rows (HAS_A), else the rows the LayerNorm reads (and the FF residual)
+  const f16* res;      // [M][ldr]: residual of stage A (A_RES)
+  f16* tok;            // [M][ldt]: stage-A output rows (HAS_A); with TAIL_FF also the feed-forward's residual
+  f16* out;            // [M][ldo]: tail output (may alias a_in / tok: a block reads and writes only its own rows)
+  const f16* wstream;  // [stage-A fragments][tail fragments]
+  const float* a_bias; // [C]   (HAS_A)
   const float* ln_g;   // [C]
   const float* ln_b;   // [C]
-  const f16* wstream;  // rcdm_pack_ff_stream
-  const float* b1p;    // [8C] packed: per (group, pair) 16 hidden biases then their 16 gate biases
-  const float* b2;     // [C]
-  int M, ldx, ldo;
+  const float* pe;     // [frames][C] (LN_PE)
+  const float* b1p;    // [8C] packed (TAIL_FF): per (group, pair) 16 hidden biases then their 16 gate biases
+  const float* b2;     // [C] (TAIL_FF)
+  int M, lda, ldr, ldt, ldo;
+  int rows_per_frame, frames;
   float eps;
 };
 
-template <int C, int NW, int PF, int R, int PD>
-__global__ __launch_bounds__(NW * 64) void ff_rows_kernel(const FFArgs p) {
-  constexpr int NK = C / 32;        // k-steps of GEMM1 = register fragments of 16 LayerNorm'ed rows
-  constexpr int NOF = C / 16;       // output fragments (16 channels each)
+template <int C, int NW, int R, int PD, bool HAS_A, bool A_RES, bool LN_PE, int TAIL>
+__global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
+  constexpr int NK = C / 32;        // k-steps of a K = C GEMM = register fragments of 16 activation rows
+  constexpr int NOF = C / 16;       // output fragments (16 channels each) of an N = C GEMM
   constexpr int CHF = 2 * NK;       // fragments per chunk (== NOF)
   constexpr int CHB = CHF * 1024;   // chunk bytes
-  constexpr int NG = C / 8;         // groups of 32 hidden units (4C / 32)
-  constexpr int NCH = 3 * NG;       // chunks: A_g / B_g = GEMM1 of the two 16 + 16 column sets of group g, C_g = GEMM2
+  constexpr int NG = C / 8;         // feed-forward: groups of 32 hidden units (4C / 32)
+  constexpr int NCH_A = HAS_A ? NK : 0;                                   // stage A: NK * NOF fragments
+  constexpr int NCH_T = TAIL == TAIL_FF ? 3 * NG : TAIL * NK;             // tail: FF 3 chunks per group; GEMM NK per C columns
+  constexpr int NCH = NCH_A + NCH_T;
   constexpr int NT = NW * 64;
   constexpr int PPW = CHF / NW;     // DMA pieces per wave and chunk
-  constexpr int WR = 16 * PF;       // rows per wave
   static_assert(CHF % NW == 0, "chunk fragments must divide over the waves");
-  static_assert(NOF == CHF, "chunk size");
-  static_assert((3 * CHF) % PD == 0, "the three chunk positions of the loop body must repeat their rotation phases");
-  static_assert(CHF >= 20, "five GEGLU slices per value");
-  constexpr int BIAS0 = R * CHB;            // b1p (8C floats), then gamma, beta (C floats each)
-  constexpr int GAM0 = BIAS0 + 8 * C * 4, BET0 = GAM0 + C * 4;
-  constexpr int RS = 2 * C + 16;            // staged output row (bytes)
-  static_assert(NW * WR * RS <= R * CHB, "epilogue staging exceeds the ring");
+  static_assert(NOF == CHF && CHF % PD == 0 && CHF >= 20 && NOF % 2 == 0, "chunk geometry");
+  constexpr int PAR0 = R * CHB;     // parameter region (floats): [a_bias C][gamma C][beta C][pe frames*C][b1p 8C]
+  constexpr int RS = 2 * C + 16;    // staged output row (bytes)
+  static_assert(NW * 16 * RS <= R * CHB, "epilogue staging exceeds the ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l15 = lane & 15, kg = lane >> 4;
-  const int row0 = blockIdx.x * (NW * WR) + wave * WR;
+  const int row0 = blockIdx.x * (NW * 16) + wave * 16;
+  const int row = row0 + l15;
+  const bool live = row < p.M;
+  const int oG = HAS_A ? C : 0, oB = oG + C, oPE = oB + C, oT = oPE + (LN_PE ? p.frames * C : 0);
+  const int npar = oT + (TAIL == TAIL_FF ? 8 * C : 0);
 
   const __amdgpu_buffer_rsrc_t rsrcW =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, (unsigned)NCH * CHB, 0x00020000);
@@ -93,21 +111,37 @@ __global__ __launch_bounds__(NW * 64) void ff_rows_kernel(const FFArgs p) {
   };
 
   // ---- prologue: plain loads first (they are waited for with the DMA prefill still in flight behind them)
-  Pack16 xr[PF][NK];
+  f16x8 xr[NK];    // the input rows; after stage A / the LayerNorm: the B operands of the tail
+  f16x8 tk[NK];    // stage A: residual in, new token rows out (P layout = operand layout)
+  auto ld16 = [](const f16* q) __attribute__((always_inline)) -> f16x8 { Pack16 t; t.u = *(const uint4*)q; return t.h; };
+  auto st16 = [](f16* q, f16x8 v) __attribute__((always_inline)) { Pack16 t; t.h = v; *(uint4*)q = t.u; };
+  {
+    const f16* xp = p.a_in + (size_t)(live ? row : 0) * p.lda + 8 * kg;
 #pragma unroll
-  for (int f = 0; f < PF; ++f) {
-    const int row = row0 + 16 * f + l15;
-    const f16* xp = p.x + (size_t)(row < p.M ? row : 0) * p.ldx + 8 * kg;
+    for (int s = 0; s < NK; ++s) xr[s] = ld16(xp + 32 * s);
+    if (HAS_A && A_RES) {
+      const f16* rp = p.res + (size_t)(live ? row : 0) * p.ldr + 8 * kg;
 #pragma unroll
-    for (int s = 0; s < NK; ++s) xr[f][s].u = *(const uint4*)(xp + 32 * s);
+      for (int s = 0; s < NK; ++s) tk[s] = ld16(rp + 32 * s);
+    } else {
+#pragma unroll
+      for (int s = 0; s < NK; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tk[s][j] = (f16)0.f;
+    }
   }
-  constexpr int NB4 = (8 * C + 2 * C) / 4;  // float4 items of [b1p | gamma | beta]
-  constexpr int NB4_PER = (NB4 + NT - 1) / NT;
+  constexpr int NB4_MAX = ((HAS_A ? C : 0) + 2 * C + (LN_PE ? 8 * C : 0) + (TAIL == TAIL_FF ? 8 * C : 0)) / 4;  // <= 8 frames
+  constexpr int NB4_PER = (NB4_MAX + NT - 1) / NT;
   f32x4 bq[NB4_PER];
 #pragma unroll
   for (int i = 0; i < NB4_PER; ++i) {
-    const int idx = min(i * NT + t, NB4 - 1);
-    const float* src = idx < 2 * C ? p.b1p + 4 * idx : (idx < 2 * C + C / 4 ? p.ln_g + 4 * (idx - 2 * C) : p.ln_b + 4 * (idx - 2 * C - C / 4));
+    const int idx = min(i * NT + t, npar / 4 - 1) * 4;
+    const float* src;
+    if (HAS_A && idx < oG) src = p.a_bias + idx;
+    else if (idx < oB) src = p.ln_g + (idx - oG);
+    else if (idx < oPE) src = p.ln_b + (idx - oB);
+    else if (LN_PE && idx < oT) src = p.pe + (idx - oPE);
+    else src = p.b1p + (idx - oT);
     bq[i] = *(const f32x4*)src;
   }
   int cslot = 0;  // slot of the chunk consumed next
@@ -116,70 +150,24 @@ __global__ __launch_bounds__(NW * 64) void ff_rows_kernel(const FFArgs p) {
 #pragma unroll
   for (int i = 0; i < NB4_PER; ++i) {
     const int idx = i * NT + t;
-    if (idx < NB4) *(f32x4*)(smem + BIAS0 + 16 * idx) = bq[i];
+    if (idx < npar / 4) *(f32x4*)(smem + PAR0 + 16 * idx) = bq[i];
   }
-
-  // LayerNorm statistics of this lane's rows (two passes over registers: mean, then squared deviations)
-  float mean[PF], rstd[PF];
-#pragma unroll
-  for (int f = 0; f < PF; ++f) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)xr[f][k].e[j];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    mean[f] = s * (1.0f / C);
-    float q = 0.f;
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = (float)xr[f][k].e[j] - mean[f];
-        q += d * d;
-      }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
-    rstd[f] = rsqrtf(q * (1.0f / C) + p.eps);
-  }
+  const float* par = (const float*)(smem + PAR0);
   wait_lgkm0();
   wait_vm<(R - 2) * PPW>();  // this wave's pieces of chunk 0 (the compiler's own wait for the plain loads came earlier)
-  tick_barrier();            // gamma / beta / b1p and chunk 0 are in LDS
-  f16x8 xf[PF][NK];
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const f32x4 g0 = *(const f32x4*)(smem + GAM0 + (32 * k + 8 * kg) * 4), g1 = *(const f32x4*)(smem + GAM0 + (32 * k + 8 * kg + 4) * 4);
-    const f32x4 b0 = *(const f32x4*)(smem + BET0 + (32 * k + 8 * kg) * 4), b1 = *(const f32x4*)(smem + BET0 + (32 * k + 8 * kg + 4) * 4);
-#pragma unroll
-    for (int f = 0; f < PF; ++f)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        xf[f][k][j] = (f16)(((float)xr[f][k].e[j] - mean[f]) * rstd[f] * g0[j] + b0[j]);
-        xf[f][k][4 + j] = (f16)(((float)xr[f][k].e[4 + j] - mean[f]) * rstd[f] * g1[j] + b1[j]);
-      }
-  }
-
-  f32x4 oacc[PF][NOF];
-#pragma unroll
-  for (int f = 0; f < PF; ++f)
-#pragma unroll
-    for (int i = 0; i < NOF; ++i) oacc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  tick_barrier();            // the parameters and chunk 0 are in LDS
 
   // ---- the weight stream is ONE software pipeline over all NCH * CHF fragments: the read of fragment f + PD is issued
-  // with the MFMAs of fragment f, across chunk boundaries (no drain at the barriers).  Chunk hand-over at the top of
-  // chunk c: this wave's pieces of chunk c + 1 have landed (counted vmcnt); the barrier makes everybody's visible — so
-  // reads may run ahead into chunk c + 1 during chunk c — and says everybody is done with chunk c - 1, whose slot the
-  // issue refills with chunk c + R - 1.  Past the end of the stream the refill pieces are out of range: they move
-  // nothing, write zeros into slots nobody reads again, and keep the counted wait the same for every chunk.
-  //
-  // Chunk order in the stream (rcdm_pack_ff_stream): A_0, then per group g: B_g, A_{g+1}, C_g  (A / B = GEMM1 of the
-  // first / second 16 hidden + 16 gate columns of the group, C = GEMM2).  The GEGLU arithmetic of a GEMM1 chunk's
-  // accumulators runs UNDER the next chunk's MFMAs (every wave of the block is in the same chunk, so VALU work placed
-  // between chunks would leave all four matrix pipes idle at once).
+  // with the MFMA of fragment f, across chunk boundaries (no drain at the barriers).  Chunk hand-over at the top of chunk
+  // c: this wave's pieces of chunk c + 1 have landed (counted vmcnt: loads only — stores complete out of order with
+  // loads, so every wait also covers the few stores issued since the previous one, which is why stores are issued right
+  // AFTER a hand-over); the barrier makes everybody's pieces visible — so reads may run ahead into chunk c + 1 during
+  // chunk c — and says everybody is done with chunk c - 1, whose slot the issue refills with chunk c + R - 1.  Past the
+  // end of the stream the refill pieces are out of range: they move nothing, write zeros into slots nobody reads again,
+  // and keep the counted wait the same for every chunk.
   int c = 0;
-  // the one lane-dependent value the loop keeps: DMA voffset and LDS read base.  Opaque, and the epilogue re-derives its
-  // lane indices from it, so that no second copy of the thread id has to survive the loop
+  // the one lane-dependent value the loops keep: DMA voffset and LDS read base.  Opaque, and the epilogue re-derives its
+  // lane indices from it, so that no second copy of the thread id has to survive the loops
   int lane16 = lane * 16;
   asm volatile("" : "+v"(lane16));
   dma_voff = lane16;
@@ -194,184 +182,299 @@ __global__ __launch_bounds__(NW * 64) void ff_rows_kernel(const FFArgs p) {
   f16x8 fr[PD];
 #pragma unroll
   for (int i = 0; i < PD; ++i) fr[i] = rd(smem + lane16 + i * 1024);
-
-  // GEGLU of one GEMM1 chunk's accumulators, h = (a_h + b_h) * gelu(a_g + b_g) for the lane's four hidden units, cut into
-  // CHF slices of 3-4 plain fp32 VALU instructions (packed fp32 issues slower next to MFMAs), one slice per MFMA step of
-  // the chunk it runs under.  gelu(x) = max(x, 0) - |x| q(|x|), q = poly(t) exp(-x^2 / 2) / 2,
-  // t = 1 / (1 + p |x| / sqrt 2)  (Abramowitz & Stegun 7.1.26, common.h gelu2).  Value e uses slices 5 e .. 5 e + 4.
-  // The empty asm statements pin every slice where the source puts it: without them the optimizer sinks the whole (pure)
-  // computation to its first use, after the chunk's MFMAs.
-  struct GegluState { float bh, x, t, pl, ex; };
-  auto geglu_slice = [&](int i, GegluState& st, const f32x4& ah, const f32x4& ag, int gp, f16* dst) __attribute__((always_inline)) {
-    const int e = i / 5, stage = i - 5 * e;
-    if (e >= 4) return;
-    const float* bp = (const float*)(smem + BIAS0 + (lane16 >> 8) * 16) + gp * 32 + e;  // this value's two biases (LDS broadcast reads)
-    if (RCDM_FF_ABLATE & 32) {
-      if (stage == 4) dst[e] = (f16)((ah[e] + bp[0]) * (ag[e] + bp[16]));
-      return;
-    }
-    if (stage == 0) {
-      st.x = ag[e] + bp[16];
-      st.bh = bp[0];
-      st.t = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(st.x), 0.2316418882f, 1.0f));
-      st.ex = st.x * st.x;
-      asm volatile("" : "+v"(st.t), "+v"(st.ex));
-    } else if (stage == 1) {
-      st.ex = __builtin_amdgcn_exp2f(st.ex * -0.72134752044f);
-      st.pl = __builtin_fmaf(st.t, 0.5307027145f, -0.7265760135f);
-      st.pl = __builtin_fmaf(st.pl, st.t, 0.7107068705f);
-      asm volatile("" : "+v"(st.pl), "+v"(st.ex));
-    } else if (stage == 2) {
-      st.pl = __builtin_fmaf(st.pl, st.t, -0.142248368f);
-      st.pl = __builtin_fmaf(st.pl, st.t, 0.127414796f);
-      st.t = st.pl * st.t;
-      asm volatile("" : "+v"(st.t));
-    } else if (stage == 3) {
-      st.t = st.t * st.ex;
-      st.pl = __builtin_fmaxf(st.x, 0.0f);
-      st.t = __builtin_fmaf(-__builtin_fabsf(st.x), st.t, st.pl);
-      asm volatile("" : "+v"(st.t));
-    } else {
-      float hv = (ah[e] + st.bh) * st.t;
-      asm volatile("" : "+v"(hv));
-      dst[e] = (f16)hv;
-    }
-  };
-  // one chunk: CHF steps of [PF MFMAs on fragment i | read of fragment i + PD | slice i of the GEGLUs], each step its own
-  // scheduling region (sched_barrier): the interleave is what the source says.
-  // PHT: the pipeline registers rotate continuously over the stream, fragment f lives in fr[f % PD]; a chunk that starts
-  // at stream fragment k CHF begins at rotation (k CHF) % PD (compile-time: register indices must be static)
-  auto run_chunk = [&](auto&& mfma_i, auto&& slice_i, auto pht) __attribute__((always_inline)) {
-    constexpr int PH = decltype(pht)::value;
+  // one chunk: CHF steps of [MFMA on fragment i | read of fragment i + PD | slice i of interleaved VALU work], each step
+  // its own scheduling region (sched_barrier): the interleave is what the source says.  post_sync: stores issued right
+  // after the hand-over.
+  auto run_chunk = [&](auto&& mfma_i, auto&& slice_i, auto&& post_sync) __attribute__((always_inline)) {
     wait_vm<(R - 3) * PPW>();
     if (!(RCDM_FF_ABLATE & 8)) tick_barrier();
     if (!(RCDM_FF_ABLATE & 1)) issue_chunk(c + R - 1, cslot == 0 ? R - 1 : cslot - 1);
+    post_sync();
     const char* sb = smem + cslot * CHB + lane16;
     const char* sn = smem + (cslot == R - 1 ? 0 : cslot + 1) * CHB + lane16;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < CHF; ++i) {
-      const f16x8 cur = fr[(i + PH) % PD];
+      const f16x8 cur = fr[i % PD];
       mfma_i(i, cur);
-      fr[(i + PH) % PD] = rd(i + PD < CHF ? sb + (i + PD) * 1024 : sn + (i + PD - CHF) * 1024);
+      fr[i % PD] = rd(i + PD < CHF ? sb + (i + PD) * 1024 : sn + (i + PD - CHF) * 1024);
       slice_i(i);
       __builtin_amdgcn_sched_barrier(0);
     }
     ++c;
     cslot = cslot == R - 1 ? 0 : cslot + 1;
   };
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  // two accumulator sets: A chunks accumulate into (ahA, agA), read by the GEGLU that runs under the following B chunk;
-  // B chunks into (ahB, agB), read under the following A chunk.  The first MFMA of a chunk takes C = 0.
-  f32x4 ahA[PF], agA[PF], ahB[PF], agB[PF];
-  union HB { f16x8 v; f16 e[8]; } hb[PF];
-  GegluState gs[PF];
-#pragma unroll
-  for (int f = 0; f < PF; ++f) ahA[f] = agA[f] = ahB[f] = agB[f] = z4;
-  auto g1A = [&](int i, f16x8 w) __attribute__((always_inline)) {
-#pragma unroll
-    for (int f = 0; f < PF; ++f) {
-      if (i & 1) agA[f] = mm(w, xf[f][i >> 1], i < 2 ? z4 : agA[f]); else ahA[f] = mm(w, xf[f][i >> 1], i < 2 ? z4 : ahA[f]);
-    }
-  };
-  auto g1B = [&](int i, f16x8 w) __attribute__((always_inline)) {
-#pragma unroll
-    for (int f = 0; f < PF; ++f) {
-      if (i & 1) agB[f] = mm(w, xf[f][i >> 1], i < 2 ? z4 : agB[f]); else ahB[f] = mm(w, xf[f][i >> 1], i < 2 ? z4 : ahB[f]);
-    }
-  };
-  auto g2 = [&](int i, f16x8 w) __attribute__((always_inline)) {
-#pragma unroll
-    for (int f = 0; f < PF; ++f) oacc[f][i] = mm(w, hb[f].v, oacc[f][i]);
-  };
   auto nothing = [&](int) __attribute__((always_inline)) {};
-  int g = 0;
-  auto sliceA = [&](int i) __attribute__((always_inline)) {
-#pragma unroll
-    for (int f = 0; f < PF; ++f) geglu_slice(i, gs[f], ahA[f], agA[f], 2 * g, hb[f].e);
-  };
-  auto sliceB = [&](int i) __attribute__((always_inline)) {
-#pragma unroll
-    for (int f = 0; f < PF; ++f) geglu_slice(i, gs[f], ahB[f], agB[f], 2 * g + 1, hb[f].e + 4);
-  };
+  auto no_stores = [&]() __attribute__((always_inline)) {};
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
-  // rotation phases of the chunk positions: A_0 is chunk 0, the loop body is chunks 3g+1 (B), 3g+2 (A), 3g+3 (C); the
-  // last group has no A chunk, so its C chunk is chunk 3 NG - 1
-  using P0 = std::integral_constant<int, 0>;
-  using PB = std::integral_constant<int, (1 * CHF) % PD>;
-  using PA = std::integral_constant<int, (2 * CHF) % PD>;
-  using PC = std::integral_constant<int, (3 * CHF) % PD>;
-  using PL = std::integral_constant<int, ((3 * NG - 1) * CHF) % PD>;
-  run_chunk(g1A, nothing, P0{});  // A_0
-  for (; g < NG - 1; ++g) {
-    run_chunk(g1B, sliceA, PB{});   // B_g under GEGLU(A_g)
-    run_chunk(g1A, sliceB, PA{});   // A_{g+1} under GEGLU(B_g)
-    run_chunk(g2, nothing, PC{});   // C_g
+  // ---- stage A: tok = a_in W_a^T + b_a (+ res), two halves of NOF / 2 output fragments (fragment order of the stream:
+  // half, k-step, fragment), accumulated in 40 registers and folded into tk (f16, P layout) after each half
+  if constexpr (HAS_A) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 acc[NOF / 2];
+#pragma unroll
+      for (int cc = 0; cc < NK / 2; ++cc)
+        run_chunk([&](int i, f16x8 w) __attribute__((always_inline)) {
+          const int s = 2 * cc + i / (NOF / 2), fi = i % (NOF / 2);
+          acc[fi] = mm(w, xr[s], s == 0 ? z4 : acc[fi]);
+        }, nothing, no_stores);
+#pragma unroll
+      for (int fi = 0; fi < NOF / 2; ++fi) {
+        const int i = h * (NOF / 2) + fi, s = i >> 1, sub = i & 1;
+        const f32x4 b = *(const f32x4*)(par + 32 * s + 8 * kg + 4 * sub);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tk[s][4 * sub + e] = (f16)(acc[fi][e] + b[e] + (float)tk[s][4 * sub + e]);
+      }
+    }
   }
-  run_chunk(g1B, sliceA, PB{});
+  // stage A's token rows go out at once (plain stores: the next hand-over's counted wait also covers them — one short
+  // stall per launch; deferring them kept 40 registers alive into the tail and spilled)
+  if (HAS_A && live) {
+    f16* tp = p.tok + (size_t)row * p.ldt + 8 * kg;
 #pragma unroll
-  for (int i = 0; i < CHF; ++i) sliceB(i);
-  run_chunk(g2, nothing, PL{});  // C of the last group
-  wait_lgkm0();
-  wait_vm<0>();    // the zero-fill pieces issued past the end of the stream
-  tick_barrier();  // every wave is done reading the ring and nothing is in flight into it
+    for (int s = 0; s < NK; ++s) st16(tp + 32 * s, tk[s]);
+  }
 
-  // ---- epilogue: accumulators -> f16 rows in this wave's private staging region -> coalesced 16-byte pass with
-  // bias + residual (the same two roundings as the unfused rcdm_gemm epilogue)
-  if (RCDM_FF_ABLATE & 16) {
-    float sacc = 0.f;
+  // ---- LayerNorm of the token rows (stage A's output, or the input rows) -> xr = the tail's B operands.  Two passes
+  // over registers (mean, then squared deviations), a row's 4 lanes combined with two cross-lane adds
+  {
+    f16x8 (&src)[NK] = HAS_A ? tk : xr;
+    float s = 0.f;
 #pragma unroll
-    for (int f = 0; f < PF; ++f)
+    for (int k = 0; k < NK; ++k)
 #pragma unroll
-      for (int i = 0; i < NOF; ++i) sacc += oacc[f][i][0] + oacc[f][i][1] + oacc[f][i][2] + oacc[f][i][3];
-    if (sacc == 1.2345678e33f) p.out[0] = (f16)sacc;
+      for (int j = 0; j < 8; ++j) s += (float)src[k][j];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = (float)src[k][j] - mean;
+        q += d * d;
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q * (1.0f / C) + p.eps);
+    const float* pep = LN_PE ? par + oPE + (((live ? row : 0) / p.rows_per_frame) % p.frames) * C : par;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int ch = 32 * k + 8 * kg;
+      const f32x4 g0 = *(const f32x4*)(par + oG + ch), g1 = *(const f32x4*)(par + oG + ch + 4);
+      f32x4 b0 = *(const f32x4*)(par + oB + ch), b1 = *(const f32x4*)(par + oB + ch + 4);
+      if (LN_PE) {
+        b0 += *(const f32x4*)(pep + ch);
+        b1 += *(const f32x4*)(pep + ch + 4);
+      }
+      f16x8 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = (f16)(((float)src[k][j] - mean) * rstd * g0[j] + b0[j]);
+        y[4 + j] = (f16)(((float)src[k][4 + j] - mean) * rstd * g1[j] + b1[j]);
+      }
+      xr[k] = y;
+    }
+  }
+
+  if constexpr (TAIL != TAIL_FF) {
+    // ---- tail GEMM  out[M][TAIL * C] = y W_t^T: groups of NOF / 2 output fragments (NK / 2 chunks each); a group's
+    // f16 results are stored 16 bytes per lane right after the next hand-over
+    constexpr int NGRP = 2 * TAIL;
+    f16x8 pend[NOF / 4];
+    int pend_col = 0;
+    auto store_pend = [&]() __attribute__((always_inline)) {
+      if (live) {
+        f16* op = p.out + (size_t)row * p.ldo + pend_col + 8 * kg;
+#pragma unroll
+        for (int m = 0; m < NOF / 4; ++m) st16(op + 32 * m, pend[m]);
+      }
+    };
+    for (int grp = 0; grp < NGRP; ++grp) {
+      f32x4 acc[NOF / 2];
+#pragma unroll
+      for (int cc = 0; cc < NK / 2; ++cc) {
+        auto mf = [&](int i, f16x8 w) __attribute__((always_inline)) {
+          const int s = 2 * cc + i / (NOF / 2), fi = i % (NOF / 2);
+          acc[fi] = mm(w, xr[s], s == 0 ? z4 : acc[fi]);
+        };
+        if (cc == 0)
+          run_chunk(mf, nothing, [&]() __attribute__((always_inline)) { if (grp > 0) store_pend(); });
+        else
+          run_chunk(mf, nothing, no_stores);
+      }
+#pragma unroll
+      for (int m = 0; m < NOF / 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pend[m][e] = (f16)acc[2 * m][e];
+          pend[m][4 + e] = (f16)acc[2 * m + 1][e];
+        }
+      pend_col = grp * (C / 2);
+    }
+    wait_lgkm0();
+    wait_vm<0>();
+    store_pend();
     return;
-  }
-  char* st = smem + wave * WR * RS;
-  const int lane_e = lane16 >> 4, l15_e = lane_e & 15, kg_e = lane_e >> 4;
+  } else {
+    // ---- tail feed-forward.  Chunk order in the stream: A_0, then per group g: B_g, A_{g+1}, C_g  (A / B = GEMM1 of the
+    // first / second 16 hidden + 16 gate columns of the group, C = GEMM2).  The GEGLU arithmetic of a GEMM1 chunk's
+    // accumulators runs UNDER the next chunk's MFMAs (every wave of the block is in the same chunk, so VALU work placed
+    // between chunks would leave all four matrix pipes idle at once), cut into CHF slices of 3-4 plain fp32 VALU
+    // instructions (packed fp32 issues slower next to MFMAs): gelu(x) = max(x, 0) - |x| q(|x|),
+    // q = poly(t) exp(-x^2 / 2) / 2, t = 1 / (1 + p |x| / sqrt 2)  (Abramowitz & Stegun 7.1.26, common.h gelu2); value e
+    // uses slices 5 e .. 5 e + 4.  The empty asm statements pin every slice where the source puts it: without them the
+    // optimizer sinks the whole (pure) computation to its first use, after the chunk's MFMAs.
+    f32x4 oacc[NOF];
 #pragma unroll
-  for (int f = 0; f < PF; ++f)
+    for (int i = 0; i < NOF; ++i) oacc[i] = z4;
+    struct GegluState { float bh, x, t, pl, ex; };
+    auto geglu_slice = [&](int i, GegluState& st, const f32x4& ah, const f32x4& ag, int gp, f16* dst) __attribute__((always_inline)) {
+      const int e = i / 5, stage = i - 5 * e;
+      if (e >= 4) return;
+      const float* bp = (const float*)(smem + PAR0 + (lane16 >> 8) * 16) + oT + gp * 32 + e;  // this value's two biases
+      if (RCDM_FF_ABLATE & 32) {
+        if (stage == 4) dst[e] = (f16)((ah[e] + bp[0]) * (ag[e] + bp[16]));
+        return;
+      }
+      if (stage == 0) {
+        st.x = ag[e] + bp[16];
+        st.bh = bp[0];
+        st.t = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(st.x), 0.2316418882f, 1.0f));
+        st.ex = st.x * st.x;
+        asm volatile("" : "+v"(st.t), "+v"(st.ex));
+      } else if (stage == 1) {
+        st.ex = __builtin_amdgcn_exp2f(st.ex * -0.72134752044f);
+        st.pl = __builtin_fmaf(st.t, 0.5307027145f, -0.7265760135f);
+        st.pl = __builtin_fmaf(st.pl, st.t, 0.7107068705f);
+        asm volatile("" : "+v"(st.pl), "+v"(st.ex));
+      } else if (stage == 2) {
+        st.pl = __builtin_fmaf(st.pl, st.t, -0.142248368f);
+        st.pl = __builtin_fmaf(st.pl, st.t, 0.127414796f);
+        st.t = st.pl * st.t;
+        asm volatile("" : "+v"(st.t));
+      } else if (stage == 3) {
+        st.t = st.t * st.ex;
+        st.pl = __builtin_fmaxf(st.x, 0.0f);
+        st.t = __builtin_fmaf(-__builtin_fabsf(st.x), st.t, st.pl);
+        asm volatile("" : "+v"(st.t));
+      } else {
+        float hv = (ah[e] + st.bh) * st.t;
+        asm volatile("" : "+v"(hv));
+        dst[e] = (f16)hv;
+      }
+    };
+    // two accumulator sets: A chunks accumulate into (ahA, agA), read by the GEGLU that runs under the following B chunk;
+    // B chunks into (ahB, agB), read under the following A chunk.  The first MFMA of a chunk takes C = 0.
+    f32x4 ahA = z4, agA = z4, ahB = z4, agB = z4;
+    union { f16x8 v; f16 e[8]; } hb;
+    GegluState gs;
+    auto g1A = [&](int i, f16x8 w) __attribute__((always_inline)) {
+      if (i & 1) agA = mm(w, xr[i >> 1], i < 2 ? z4 : agA); else ahA = mm(w, xr[i >> 1], i < 2 ? z4 : ahA);
+    };
+    auto g1B = [&](int i, f16x8 w) __attribute__((always_inline)) {
+      if (i & 1) agB = mm(w, xr[i >> 1], i < 2 ? z4 : agB); else ahB = mm(w, xr[i >> 1], i < 2 ? z4 : ahB);
+    };
+    auto g2 = [&](int i, f16x8 w) __attribute__((always_inline)) { oacc[i] = mm(w, hb.v, oacc[i]); };
+    int g = 0;
+    auto sliceA = [&](int i) __attribute__((always_inline)) { geglu_slice(i, gs, ahA, agA, 2 * g, hb.e); };
+    auto sliceB = [&](int i) __attribute__((always_inline)) { geglu_slice(i, gs, ahB, agB, 2 * g + 1, hb.e + 4); };
+    run_chunk(g1A, nothing, no_stores);  // A_0
+    for (; g < NG - 1; ++g) {
+      run_chunk(g1B, sliceA, no_stores);   // B_g under GEGLU(A_g)
+      run_chunk(g1A, sliceB, no_stores);   // A_{g+1} under GEGLU(B_g)
+      run_chunk(g2, nothing, no_stores);   // C_g
+    }
+    run_chunk(g1B, sliceA, no_stores);
+#pragma unroll
+    for (int i = 0; i < CHF; ++i) sliceB(i);
+    run_chunk(g2, nothing, no_stores);  // C of the last group
+    wait_lgkm0();
+    wait_vm<0>();    // the zero-fill pieces issued past the end of the stream (and stage A's stores)
+    tick_barrier();  // every wave is done reading the ring and nothing is in flight into it
+
+    // ---- epilogue: accumulators -> f16 rows in this wave's private staging region -> coalesced 16-byte pass with
+    // bias + residual (the same two roundings as the unfused rcdm_gemm epilogue).  The residual rows were written by
+    // this block's stage A when there is one: read back past the vector L1 (sc1)
+    if (RCDM_FF_ABLATE & 16) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < NOF; ++i) sacc += oacc[i][0] + oacc[i][1] + oacc[i][2] + oacc[i][3];
+      if (sacc == 1.2345678e33f) p.out[0] = (f16)sacc;
+      return;
+    }
+    char* st = smem + wave * 16 * RS;
+    const int lane_e = lane16 >> 4, l15_e = lane_e & 15, kg_e = lane_e >> 4;
 #pragma unroll
     for (int i = 0; i < NOF; ++i) {
       union { f16 h[4]; uint2 u; } pk;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pk.h[e] = (f16)oacc[f][i][e];
-      *(uint2*)(st + (16 * f + l15_e) * RS + (16 * i + 4 * kg_e) * 2) = pk.u;
+      for (int e = 0; e < 4; ++e) pk.h[e] = (f16)oacc[i][e];
+      *(uint2*)(st + l15_e * RS + (16 * i + 4 * kg_e) * 2) = pk.u;
     }
-  wait_lgkm0();
-  constexpr int CPR = C / 8, ITEMS = WR * CPR, NIT = (ITEMS + 63) / 64;
-  constexpr int U = 5;  // residual loads in flight per lane
-  static_assert(NIT % U == 0, "epilogue batches");
-  for (int it0 = 0; it0 < NIT; it0 += U) {
-    Pack16 rr[U];
+    wait_lgkm0();
+    const f16* rbase = HAS_A ? p.tok : p.a_in;
+    const int ldres = HAS_A ? p.ldt : p.lda;
+    const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc((void*)rbase, 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int CPR = C / 8, ITEMS = 16 * CPR, NIT = (ITEMS + 63) / 64;
+    constexpr int U = 5;  // residual loads in flight per lane
+    static_assert(NIT % U == 0, "epilogue batches");
+    for (int it0 = 0; it0 < NIT; it0 += U) {
+      Pack16 rr[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = min((it0 + u) * 64 + lane_e, ITEMS - 1);
-      const int r = idx / CPR, c8 = idx - r * CPR;
-      const int m = min(row0 + r, p.M - 1);
-      rr[u].u = *(const uint4*)(p.x + (size_t)m * p.ldx + c8 * 8);
-    }
+      for (int u = 0; u < U; ++u) {
+        const int idx = min((it0 + u) * 64 + lane_e, ITEMS - 1);
+        const int r = idx / CPR, c8 = idx - r * CPR;
+        const int m = min(row0 + r, p.M - 1);
+        rr[u].v = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (m * ldres + c8 * 8) * 2, 0, HAS_A ? 16 : 0);
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = (it0 + u) * 64 + lane_e;
-      const int r = idx / CPR, c8 = idx - r * CPR;
-      const int m = row0 + r;
-      if (idx < ITEMS && m < p.M) {
-        Pack16 v, o;
-        v.u = *(const uint4*)(st + r * RS + c8 * 16);
-        const f32x4 a0 = *(const f32x4*)(p.b2 + c8 * 8), a1 = *(const f32x4*)(p.b2 + c8 * 8 + 4);
+      for (int u = 0; u < U; ++u) {
+        const int idx = (it0 + u) * 64 + lane_e;
+        const int r = idx / CPR, c8 = idx - r * CPR;
+        const int m = row0 + r;
+        if (idx < ITEMS && m < p.M) {
+          Pack16 v, o;
+          v.u = *(const uint4*)(st + r * RS + c8 * 16);
+          const f32x4 a0 = *(const f32x4*)(p.b2 + c8 * 8), a1 = *(const f32x4*)(p.b2 + c8 * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o.e[e] = (f16)((float)v.e[e] + a0[e] + (float)rr[u].e[e]);
-          o.e[4 + e] = (f16)((float)v.e[4 + e] + a1[e] + (float)rr[u].e[4 + e]);
+          for (int e = 0; e < 4; ++e) {
+            o.e[e] = (f16)((float)v.e[e] + a0[e] + (float)rr[u].e[e]);
+            o.e[4 + e] = (f16)((float)v.e[4 + e] + a1[e] + (float)rr[u].e[4 + e]);
+          }
+          *(uint4*)(p.out + (size_t)m * p.ldo + c8 * 8) = o.u;
         }
-        *(uint4*)(p.out + (size_t)m * p.ldo + c8 * 8) = o.u;
       }
     }
   }
 }
 
-// fp32 [8C][C] / [8C] / [C][4C] -> the fragment-major stream + packed bias the kernel consumes
+// ---- weight packing: fp32 reference layouts -> the fragment-major streams the kernel consumes ------------------------
+// One fragment = 16 output rows x 32 k values as the v_mfma_f32_16x16x32_f16 A operand: lane L = (row l15 = L & 15,
+// k-group kq = L >> 4) holds k = 32 s + 8 kq .. + 7.
+
+// N = C GEMM blocks in the P layout (stage A, tail GEMM): n_blocks blocks of C output channels; fragment order per block:
+// half (NOF / 2 fragments), k-step, fragment.  Fragment i of a block, D row r  <->  channel 32 (i >> 1) + 8 (r >> 2) +
+// 4 (i & 1) + (r & 3) of the block.
+__global__ void pack_pgemm_kernel(const float* __restrict__ w, int C, int n_blocks, f16* __restrict__ ws) {
+  const int NK = C / 32, NOF = C / 16, HF = NOF / 2;
+  const size_t per_block = (size_t)NOF * NK * 512, total = per_block * n_blocks;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(idx & 7), L = (int)((idx >> 3) & 63);
+    const size_t fq = idx >> 9;
+    const int blk = (int)(fq / (NOF * NK)), f = (int)(fq % (NOF * NK));
+    const int h = f / (HF * NK), rem = f % (HF * NK), s = rem / HF, fi = rem % HF;
+    const int i = h * HF + fi, r = L & 15, kq = L >> 4;
+    const int n = blk * C + 32 * (i >> 1) + 8 * (r >> 2) + 4 * (i & 1) + (r & 3);
+    ws[idx] = (f16)w[(size_t)n * C + 32 * s + 8 * kq + j];
+  }
+}
+
+// feed-forward: fp32 [8C][C] / [8C] / [C][4C] -> chunks A_0, then per group g: B_g, A_{g+1} (absent for the last group),
+// C_g; the k-slots of the GEMM2 fragments follow the D layout of the GEGLU values
 __global__ void pack_ff_stream_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                       int C, f16* __restrict__ ws, float* __restrict__ b1p) {
   const int NK = C / 32, CHF = 2 * NK;
@@ -380,7 +483,6 @@ __global__ void pack_ff_stream_kernel(const float* __restrict__ w1, const float*
     const int j = (int)(idx & 7), L = (int)((idx >> 3) & 63);
     const size_t fr = idx >> 9;
     const int f = (int)(fr % CHF), c = (int)(fr / CHF);
-    // chunk order: A_0, then per group g: B_g, A_{g+1} (absent for the last group), C_g
     int g, part;  // part 0 = A (first 16 hidden + gate columns of the group), 1 = B (second 16), 2 = C (GEMM2)
     if (c == 0) { g = 0; part = 0; }
     else {
@@ -411,51 +513,68 @@ __global__ void pack_ff_stream_kernel(const float* __restrict__ w1, const float*
   }
 }
 
-template <int C, int NW, int PF, int R, int PD>
-int launch_ff(const FFArgs& a, hipStream_t stream) {
+template <bool HAS_A, bool A_RES, bool LN_PE, int TAIL>
+int launch_chain(const RowArgs& a, hipStream_t stream) {
+  constexpr int C = 320, NW = 10, R = 7, PD = 2;
   constexpr int CHB = 2 * (C / 32) * 1024;
-  constexpr int LDS = R * CHB + 10 * C * 4;
-  static_assert(LDS <= 160 * 1024, "LDS");
+  const int npar = (HAS_A ? C : 0) + 2 * C + (LN_PE ? a.frames * C : 0) + (TAIL == TAIL_FF ? 8 * C : 0);
+  const int lds = R * CHB + npar * 4;
+  if (lds > 160 * 1024) return RCDM_ESHAPE;
   int dev = 0;
   (void)hipGetDevice(&dev);
   static bool attr_set[64] = {};
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    if (hipFuncSetAttribute((const void*)ff_rows_kernel<C, NW, PF, R, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess)
+    if (hipFuncSetAttribute((const void*)row_chain_kernel<C, NW, R, PD, HAS_A, A_RES, LN_PE, TAIL>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return RCDM_ELAUNCH;
     attr_set[dev] = true;
   }
-  const int rows = NW * 16 * PF;
-  const int nblocks = (a.M + rows - 1) / rows;
-  hipLaunchKernelGGL((ff_rows_kernel<C, NW, PF, R, PD>), dim3(nblocks), dim3(NW * 64), LDS, stream, a);
+  const int nblocks = (a.M + NW * 16 - 1) / (NW * 16);
+  hipLaunchKernelGGL((row_chain_kernel<C, NW, R, PD, HAS_A, A_RES, LN_PE, TAIL>), dim3(nblocks), dim3(NW * 64), lds, stream, a);
   return rcdm_check_launch();
 }
 
-int g_ff_variant = -1;  // -1: automatic (= 0); 0: 10 waves x 16 rows; 1: 4 waves x 48 rows
+inline unsigned grid_for(size_t n) {
+  size_t g = (n + 255) / 256;
+  return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
 
 }  // namespace
 
 extern "C" {
 
+int rcdm_ff_fused_supported(int32_t C) { return C == 320 ? 1 : 0; }
+int rcdm_rowchain_supported(int32_t C) { return C == 320 ? 1 : 0; }
+
 size_t rcdm_ff_stream_bytes(int32_t C) { return C > 0 ? (size_t)24 * C * C : 0; }
 
-int rcdm_ff_fused_supported(int32_t C) { return C == 320 ? 1 : 0; }
-
-int rcdm_set_ff_variant(int32_t v) {
-  if (v < -1 || v > 1) return RCDM_EINVAL;
-  g_ff_variant = v;
-  return RCDM_OK;
+size_t rcdm_rowchain_stream_bytes(int32_t C, int32_t tail) {
+  if (C <= 0 || !(tail == 0 || tail == 1 || tail == 3)) return 0;
+  return (size_t)2 * C * C * (1 + (tail == 0 ? 12 : tail));
 }
 
 int rcdm_pack_ff_stream(const float* w1, const float* b1, const float* w2, int32_t C, void* wstream, float* b1_packed,
                         void* stream) {
   if (!w1 || !b1 || !w2 || !wstream || !b1_packed || C <= 0) return RCDM_EINVAL;
   if (C % 32) return RCDM_ESHAPE;
-  const size_t n = (size_t)12 * C * C;
-  size_t g = (n + 255) / 256;
-  if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(pack_ff_stream_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, C, (f16*)wstream,
-                     b1_packed);
+  hipLaunchKernelGGL(pack_ff_stream_kernel, dim3(grid_for((size_t)12 * C * C)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, C,
+                     (f16*)wstream, b1_packed);
+  return rcdm_check_launch();
+}
+
+int rcdm_pack_rowchain(const float* wa, int32_t C, int32_t tail, const float* wt, const float* w1, const float* b1,
+                       const float* w2, void* wstream, float* b1_packed, void* stream) {
+  if (!wa || !wstream || C <= 0) return RCDM_EINVAL;
+  if (C % 32 || !(tail == 0 || tail == 1 || tail == 3)) return RCDM_ESHAPE;
+  if (tail == 0 ? (!w1 || !b1 || !w2 || !b1_packed) : !wt) return RCDM_EINVAL;
+  f16* ws = (f16*)wstream;
+  hipLaunchKernelGGL(pack_pgemm_kernel, dim3(grid_for((size_t)C * C)), dim3(256), 0, (hipStream_t)stream, wa, C, 1, ws);
+  ws += (size_t)C * C;
+  if (tail == 0)
+    hipLaunchKernelGGL(pack_ff_stream_kernel, dim3(grid_for((size_t)12 * C * C)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, C,
+                       ws, b1_packed);
+  else
+    hipLaunchKernelGGL(pack_pgemm_kernel, dim3(grid_for((size_t)tail * C * C)), dim3(256), 0, (hipStream_t)stream, wt, C, tail, ws);
   return rcdm_check_launch();
 }
 
@@ -463,15 +582,39 @@ int rcdm_ff_fused(const rcdm_ff_desc* d, const void* x, const float* ln_gamma, c
                   const float* b1_packed, const float* b2, void* out, void* stream) {
   if (!d || !x || !ln_gamma || !ln_beta || !wstream || !b1_packed || !b2 || !out) return RCDM_EINVAL;
   if (d->M <= 0 || d->ldx < d->C || d->ldo < d->C || (d->ldx & 7) || (d->ldo & 7)) return RCDM_EINVAL;
-  FFArgs a{(const f16*)x, (f16*)out, ln_gamma, ln_beta, (const f16*)wstream, b1_packed, b2, d->M, d->ldx, d->ldo, d->eps};
-  switch (d->C) {
-    case 320:
-      // measured (tools/kbench.py ff, 40960 rows): ten waves x 16 rows 118 us, four waves x 48 rows 147 us (one wave per
-      // SIMD issues one instruction per ~4 clocks: MFMAs + GEGLU arithmetic + reads do not fit), the unfused chain 163 + 15
-      if (g_ff_variant == 1) return launch_ff<320, 4, 3, 7, RCDM_FF_PD>(a, (hipStream_t)stream);
-      return launch_ff<320, 10, 1, 7, 2>(a, (hipStream_t)stream);
-    default: return RCDM_ESHAPE;
+  if (d->C != 320) return RCDM_ESHAPE;
+  RowArgs a{};
+  a.a_in = (const f16*)x; a.out = (f16*)out; a.wstream = (const f16*)wstream;
+  a.ln_g = ln_gamma; a.ln_b = ln_beta; a.b1p = b1_packed; a.b2 = b2;
+  a.M = d->M; a.lda = d->ldx; a.ldo = d->ldo; a.rows_per_frame = 1; a.frames = 1; a.eps = d->eps;
+  return launch_chain<false, false, false, TAIL_FF>(a, (hipStream_t)stream);
+}
+
+int rcdm_rowchain(const rcdm_rowchain_desc* d, const void* a_in, const void* res, void* tok, const float* a_bias,
+                  const float* ln_gamma, const float* ln_beta, const float* pe, const void* wstream, const float* b1_packed,
+                  const float* b2, void* out, void* stream) {
+  if (!d || !a_in || !tok || !a_bias || !ln_gamma || !ln_beta || !wstream || !out) return RCDM_EINVAL;
+  const int ncol = d->tail == 0 ? d->C : d->tail * d->C;
+  if (d->M <= 0 || d->lda < d->C || d->ldt < d->C || d->ldo < ncol || ((d->lda | d->ldt | d->ldo) & 7)) return RCDM_EINVAL;
+  if (res && (d->ldr < d->C || (d->ldr & 7))) return RCDM_EINVAL;
+  if (pe && (d->rows_per_frame <= 0 || d->frames <= 0 || d->frames > 8)) return RCDM_EINVAL;
+  if (d->tail == 0 && (!b1_packed || !b2)) return RCDM_EINVAL;
+  if (d->C != 320 || !(d->tail == 0 || d->tail == 1 || d->tail == 3)) return RCDM_ESHAPE;
+  RowArgs a{};
+  a.a_in = (const f16*)a_in; a.res = (const f16*)res; a.tok = (f16*)tok; a.out = (f16*)out; a.wstream = (const f16*)wstream;
+  a.a_bias = a_bias; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.pe = pe; a.b1p = b1_packed; a.b2 = b2;
+  a.M = d->M; a.lda = d->lda; a.ldr = d->ldr; a.ldt = d->ldt; a.ldo = d->ldo;
+  a.rows_per_frame = pe ? d->rows_per_frame : 1; a.frames = pe ? d->frames : 1; a.eps = d->eps;
+  hipStream_t s = (hipStream_t)stream;
+#define RCDM_CHAIN(T)                                                                  \
+  (res ? (pe ? launch_chain<true, true, true, T>(a, s) : launch_chain<true, true, false, T>(a, s)) \
+       : (pe ? launch_chain<true, false, true, T>(a, s) : launch_chain<true, false, false, T>(a, s)))
+  switch (d->tail) {
+    case 0: return RCDM_CHAIN(TAIL_FF);
+    case 1: return RCDM_CHAIN(TAIL_N1);
+    default: return RCDM_CHAIN(TAIL_N3);
   }
+#undef RCDM_CHAIN
 }
 
 }  // extern "C"

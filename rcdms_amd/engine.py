@@ -321,6 +321,34 @@ class Packer:
         self._tmp += [w1, b1, w2]
         return ws, b1p
 
+    def chain(self, wa_key, tail, wt_keys=(), ff_keys=None):
+        """(weight stream, packed b1 | None) for rcdm_rowchain: stage-A matrix wa_key [C][C] (a Linear or 1x1 conv weight),
+        then tail 1 / 3: the stacked [tail*C][C] matrices wt_keys, tail 0: the feed-forward (w1, b1, w2) keys.  None when
+        the library has no chain kernel for this width or a tail projection carries a bias."""
+        if not ROW_CHAIN or any(not self.has(k) for k in (wa_key, *wt_keys, *(ff_keys or ()))):
+            return None
+        Cc = self.sd[wa_key].shape[0]
+        if not hip.rowchain_supported(Cc) or self.sd[wa_key].numel() != Cc * Cc:
+            return None
+        if any(self.has(k.replace(".weight", ".bias")) for k in wt_keys):
+            return None
+        wa = self.f32(wa_key).reshape(Cc, Cc).contiguous()
+        ws = torch.empty(hip.rowchain_stream_bytes(Cc, tail), dtype=torch.uint8, device=self.device)
+        if tail:
+            wt = torch.cat([self.f32(k) for k in wt_keys], dim=0).contiguous()
+            if tuple(wt.shape) != (tail * Cc, Cc):
+                return None
+            hip.pack_rowchain(wa.data_ptr(), Cc, tail, wt.data_ptr(), 0, 0, 0, ws.data_ptr(), 0)
+            self._tmp += [wa, wt]
+            return ws, None
+        w1, b1, w2 = (self.f32(k) for k in ff_keys)
+        if w1.shape != (8 * Cc, Cc) or w2.shape != (Cc, 4 * Cc):
+            return None
+        b1p = torch.empty(8 * Cc, dtype=torch.float32, device=self.device)
+        hip.pack_rowchain(wa.data_ptr(), Cc, 0, 0, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), ws.data_ptr(), b1p.data_ptr())
+        self._tmp += [wa, w1, b1, w2]
+        return ws, b1p
+
     def done(self):
         torch.cuda.synchronize(self.device)
         self._tmp.clear()
@@ -379,11 +407,19 @@ def pack_basic_block(pk, b):
     else:
         w.ff1, w.ff1_b = pk.mat_f16(b + "ff.net.0.proj.weight"), pk.vec(b + "ff.net.0.proj.bias")
     w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
+    # row-stationary chains: attn1.to_out + res -> norm2 -> attn2.to_q, and attn2.to_out + res -> norm3 -> ff -> + res
+    w.ch_in_qkv = w.ch_o1_q = w.ch_o2_ff = None
+    if w.has_cross and w.geglu:
+        w.ch_o1_q = pk.chain(b + "attn1.to_out.0.weight", 1, wt_keys=(b + "attn2.to_q.weight",))
+        w.ch_o2_ff = pk.chain(b + "attn2.to_out.0.weight", 0,
+                              ff_keys=(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight"))
     return w
 
 
 def pack_transformer(pk, p):
     w = pack_basic_block(pk, p + "transformer_blocks.0.")
+    b = p + "transformer_blocks.0.attn1."
+    w.ch_in_qkv = pk.chain(p + "proj_in.weight", 3, wt_keys=(b + "to_q.weight", b + "to_k.weight", b + "to_v.weight"))
     w.gn_g, w.gn_b = pk.vec(p + "norm.weight"), pk.vec(p + "norm.bias")
     w.proj_in, w.proj_in_b = pk.mat_f16(p + "proj_in.weight"), pk.vec(p + "proj_in.bias")
     w.proj_out, w.proj_out_b = pk.mat_f16(p + "proj_out.weight"), pk.vec(p + "proj_out.bias")
@@ -412,6 +448,17 @@ def pack_motion(pk, p, n_attn):
     w.ff1, w.ff1_b = pk.geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias")
     w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
     w.ff_stream = pk.ff_stream(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight")
+    # row-stationary chains: proj_in -> norms[0] + pe -> qkv;  to_out + res -> norms[1] + pe -> qkv;  to_out + res ->
+    # ff_norm -> ff -> + res
+    w.chains = None
+    if n_attn == 2:
+        a0, a1 = b + "attention_blocks.0.", b + "attention_blocks.1."
+        qkv = lambda a: (a + "to_q.weight", a + "to_k.weight", a + "to_v.weight")
+        ch = [pk.chain(p + "proj_in.weight", 3, wt_keys=qkv(a0)), pk.chain(a0 + "to_out.0.weight", 3, wt_keys=qkv(a1)),
+              pk.chain(a1 + "to_out.0.weight", 0,
+                       ff_keys=(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight"))]
+        if all(c is not None for c in ch) and all(at.pe is not None for at in w.attn):
+            w.chains = ch
     return w
 
 
@@ -450,6 +497,26 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
 # rcdm_ff_fused (rowff.hip): LayerNorm -> GEGLU feed-forward -> + residual as ONE row-stationary launch, for the channel
 # counts the library has a kernel for.  RCDM_FF_FUSE=0 keeps the three-launch chain (same-process A/B).
 FF_FUSE = os.environ.get("RCDM_FF_FUSE", "1") != "0"
+# rcdm_rowchain (rowff.hip): [C x C projection (+ residual) -> LayerNorm (+ pe) -> q | qkv projection or feed-forward] as one
+# row-stationary launch.  RCDM_ROWCHAIN=0 keeps the separate launches (same-process A/B).
+ROW_CHAIN = os.environ.get("RCDM_ROWCHAIN", "1") != "0"
+
+
+def emit_rowchain(plan, a_in, res, tok, a_bias, ln, pe, stream, tail, out, rows_per_frame=1, frames=1, b2=None):
+    """tok = a_in W_a^T + a_bias (+ res);  y = LayerNorm(tok) (+ pe);  tail 1 / 3: out = y W_t^T;  tail 0: out = tok + FF(y).
+    ln = (gamma, beta); stream = Packer.chain(...)."""
+    ws, b1p = stream
+    M, C = a_in.M, a_in.C
+    d = hip.RowChainDesc(M, C, a_in.ld, res.ld if res is not None else 0, tok.ld, out.ld, tail, rows_per_frame, frames, 1e-5)
+
+    def op():
+        hip.rowchain(d, a_in.ptr, res.ptr if res is not None else 0, tok.ptr, a_bias.data_ptr(), ln[0].data_ptr(),
+                     ln[1].data_ptr(), pe.data_ptr() if pe is not None else 0, ws.data_ptr(),
+                     b1p.data_ptr() if b1p is not None else 0, b2.data_ptr() if b2 is not None else 0, out.ptr)
+    plan.add(op, f"rowchain M={M} C={C} tail={tail} res={int(res is not None)} pe={int(pe is not None)}")
+    plan.keep += [a_bias, ln[0], ln[1], pe, ws, b1p, b2]
+    plan.n_launch += 1
+    plan.last_gemm = None
 
 
 def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None):
@@ -472,7 +539,7 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None)
     emit_gemm(plan, gg, ff2, C, 4 * C, tok, bias=ff2_b, residual=tok)
 
 
-def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False, ctx_img=None):
+def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False, ctx_img=None, pre=None):
     """BasicTransformerBlock.forward (src/models/attention.py:479-526) in place on tok [n_seq*Lq][C]:
     h += attn1(LN1(h)); h += attn2(LN2(h), ctx); h += FF(LN3(h)).  ctx_kv: Rows [n_seq*L][2C] = [K | V] of the context.
     shared_half: the two halves of tok (the CFG halves of a denoising step) hold IDENTICAL rows on entry — everything up
@@ -484,21 +551,33 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
         assert w.has_cross and n_seq % 2 == 0
         ns, Ms, dup = n_seq // 2, M // 2, M // 2
     ao = plan.rows("attn_out", M, C)
-    # self-attention over the Lq tokens of each sequence
-    emit_layernorm(plan, tok.rows(0, Ms), w.ln[0][0], w.ln[0][1], a.rows(0, Ms))
+    # self-attention over the Lq tokens of each sequence.  pre = (rows, bias): tok = rows proj_in^T + bias has NOT been
+    # emitted yet and rides in the chain launch with norm1 and the q | k | v projection
     qkv = plan.rows("qkv", M, 3 * C).rows(0, Ms)
-    emit_gemm(plan, a.rows(0, Ms), w.qkv1, 3 * C, C, qkv, bias=w.qkv1_b)
+    if pre is not None:
+        emit_rowchain(plan, pre[0], None, tok, pre[1], w.ln[0], None, w.ch_in_qkv, 3, qkv)
+    else:
+        emit_layernorm(plan, tok.rows(0, Ms), w.ln[0][0], w.ln[0][1], a.rows(0, Ms))
+        emit_gemm(plan, a.rows(0, Ms), w.qkv1, 3 * C, C, qkv, bias=w.qkv1_b)
     emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), ns, heads, Lq, Lq, d_head, ao.rows(0, Ms))
-    emit_gemm(plan, ao.rows(0, Ms), w.o1, C, C, tok.rows(0, Ms), bias=w.o1_b, residual=tok.rows(0, Ms), dup_rows=dup)
+    chain_q = w.has_cross and w.ch_o1_q is not None and not shared_half
+    if not chain_q:
+        emit_gemm(plan, ao.rows(0, Ms), w.o1, C, C, tok.rows(0, Ms), bias=w.o1_b, residual=tok.rows(0, Ms), dup_rows=dup)
     if w.has_cross:
         # cross-attention over the L context rows of that sequence
-        emit_layernorm(plan, tok.rows(0, Ms), w.ln[1][0], w.ln[1][1], a.rows(0, Ms))
         qc = plan.rows("qkv", M, C)
-        emit_gemm(plan, a.rows(0, Ms), w.q2, C, C, qc.rows(0, Ms), bias=w.q2_b, dup_rows=dup)
+        if chain_q:   # attn1.to_out + residual -> norm2 -> attn2.to_q in one launch
+            emit_rowchain(plan, ao, tok, tok, w.o1_b, w.ln[1], None, w.ch_o1_q, 1, qc)
+        else:
+            emit_layernorm(plan, tok.rows(0, Ms), w.ln[1][0], w.ln[1][1], a.rows(0, Ms))
+            emit_gemm(plan, a.rows(0, Ms), w.q2, C, C, qc.rows(0, Ms), bias=w.q2_b, dup_rows=dup)
         if ctx_img is not None:   # short context: the per-context fragment image (emit_ctx_kv), scores in registers
             emit_xattn(plan, qc, ctx_img, n_seq, heads, Lq, L, d_head, ao)
         else:
             emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), n_seq, heads, Lq, L, d_head, ao)
+        if w.ch_o2_ff is not None:   # attn2.to_out + residual -> norm3 -> ff -> + residual in one launch
+            emit_rowchain(plan, ao, tok, tok, w.o2_b, w.ln[2], None, w.ch_o2_ff, 0, tok, b2=w.ff2_b)
+            return
         emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok)
     if w.geglu:
         emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, M, C, stream=w.ff_stream)
@@ -518,8 +597,12 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     a = plan.rows("norm", g.M, C)
     emit_groupnorm(plan, x.rows(0, M_s), n_s, g.hw, w.gn_g, w.gn_b, 1e-6, False, a.rows(0, M_s), groups)
     tok = plan.rows("tok", g.M, C)
-    emit_gemm(plan, a.rows(0, M_s), w.proj_in, C, C, tok.rows(0, M_s), bias=w.proj_in_b)
-    emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img)
+    pre = None
+    if w.ch_in_qkv is not None and not shared_half:
+        pre = (a, w.proj_in_b)       # proj_in rides with norm1 + qkv (emit_basic_block)
+    else:
+        emit_gemm(plan, a.rows(0, M_s), w.proj_in, C, C, tok.rows(0, M_s), bias=w.proj_in_b)
+    emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img, pre=pre)
     emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
 
 
@@ -544,6 +627,18 @@ def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
     else:
         emit_groupnorm(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, False, a, groups)
     tok = plan.rows("tok", g.M, C)
+    if w.chains is not None and not prior_state:
+        # three chain launches + two temporal attentions + proj_out instead of twelve launches
+        qkv = plan.rows("qkv", g.M, 3 * C)
+        ao = plan.rows("attn_out", g.M, C)
+        a0, a1 = w.attn
+        emit_rowchain(plan, a, None, tok, w.proj_in_b, (a0.ln_g, a0.ln_b), a0.pe, w.chains[0], 3, qkv, g.hw, g.f)
+        emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)
+        emit_rowchain(plan, ao, tok, tok, a0.o_b, (a1.ln_g, a1.ln_b), a1.pe, w.chains[1], 3, qkv, g.hw, g.f)
+        emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)
+        emit_rowchain(plan, ao, tok, tok, a1.o_b, w.ff_ln, None, w.chains[2], 0, tok, b2=w.ff2_b)
+        emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
+        return
     emit_gemm(plan, a, w.proj_in, C, C, tok, bias=w.proj_in_b)
     for at in w.attn:
         emit_layernorm(plan, tok, at.ln_g, at.ln_b, a, pe=at.pe, rows_per_frame=g.hw, frames=g.f)

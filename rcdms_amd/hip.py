@@ -54,6 +54,12 @@ class FFDesc(C.Structure):
     _fields_ = [("M", C.c_int32), ("C", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32), ("eps", C.c_float)]
 
 
+class RowChainDesc(C.Structure):
+    _fields_ = [("M", C.c_int32), ("C", C.c_int32), ("lda", C.c_int32), ("ldr", C.c_int32), ("ldt", C.c_int32),
+                ("ldo", C.c_int32), ("tail", C.c_int32), ("rows_per_frame", C.c_int32), ("frames", C.c_int32),
+                ("eps", C.c_float)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("heads", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
                 ("d", C.c_int32), ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32),
@@ -90,9 +96,12 @@ SYMBOLS = {
     "rcdm_temporal_attn": (C.c_int, [C.POINTER(TemporalAttnDesc), _P, _P, _P]),
     "rcdm_ff_stream_bytes": (_SZ, [_I]),
     "rcdm_ff_fused_supported": (C.c_int, [_I]),
-    "rcdm_set_ff_variant": (C.c_int, [_I]),
     "rcdm_pack_ff_stream": (C.c_int, [_P, _P, _P, _I, _P, _P, _P]),
     "rcdm_ff_fused": (C.c_int, [C.POINTER(FFDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rcdm_rowchain_supported": (C.c_int, [_I]),
+    "rcdm_rowchain_stream_bytes": (_SZ, [_I, _I]),
+    "rcdm_pack_rowchain": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "rcdm_rowchain": (C.c_int, [C.POINTER(RowChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rcdm_timestep_embed": (C.c_int, [_P, _I, _I, _P, _P]),
     "rcdm_small_linear": (C.c_int, [_P, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "rcdm_assemble_input": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -244,8 +253,22 @@ def ff_fused_supported(Cc):
     return bool(load().rcdm_ff_fused_supported(Cc))
 
 
-def set_ff_variant(v):
-    _check(load().rcdm_set_ff_variant(v), "rcdm_set_ff_variant")
+def rowchain_supported(Cc):
+    return bool(load().rcdm_rowchain_supported(Cc))
+
+
+def rowchain_stream_bytes(Cc, tail):
+    return load().rcdm_rowchain_stream_bytes(Cc, tail)
+
+
+def pack_rowchain(wa, Cc, tail, wt, w1, b1, w2, wstream, b1p, stream=None):
+    _check(load().rcdm_pack_rowchain(wa, Cc, tail, wt, w1, b1, w2, wstream, b1p,
+                                     stream_ptr() if stream is None else stream), "rcdm_pack_rowchain")
+
+
+def rowchain(desc, a_in, res, tok, a_bias, ln_g, ln_b, pe, wstream, b1p, b2, out, stream=None):
+    _check(load().rcdm_rowchain(C.byref(desc), a_in, res, tok, a_bias, ln_g, ln_b, pe, wstream, b1p, b2, out,
+                                stream_ptr() if stream is None else stream), "rcdm_rowchain")
 
 
 def pack_ff_stream(w1, b1, w2, Cc, wstream, b1p, stream=None):

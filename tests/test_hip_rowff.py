@@ -45,11 +45,9 @@ def _run_fused(x16, ld, w, out=None, M=None):
     return out
 
 
-@pytest.mark.parametrize("variant", [0, 1])           # ten waves x 16 rows | four waves x 48 rows per block
 @pytest.mark.parametrize("M", [160, 16, 333, 2560])   # one block; one wave; ragged tail; many blocks
-def test_ff_fused_vs_reference(hiplib, M, variant):
+def test_ff_fused_vs_reference(hiplib, M):
     from rcdms_amd import hip
-    hip.set_ff_variant(variant)
     C = 320
     assert hip.ff_fused_supported(C)
     w, g = _weights(C, 11 + M)
@@ -60,7 +58,6 @@ def test_ff_fused_vs_reference(hiplib, M, variant):
     xb[:M, :C] = x.half().to(DEV)
     out = torch.full((M + 8, ld), 7.0, dtype=torch.float16, device=DEV)
     _run_fused(xb, ld, w, out, M=M)
-    hip.set_ff_variant(-1)
     close(out[:M, :C], ref)
     assert (out[M:] == 7.0).all() and (out[:, C:] == 7.0).all(), "stores outside the M x C result"
 
@@ -107,3 +104,105 @@ def test_ff_fused_deterministic_and_rejects(hiplib):
     with pytest.raises(hip.RcdmError):
         hip.ff_fused(hip.FFDesc(M, 64, 64, 64, 1e-5), x16.data_ptr(), x16.data_ptr(), x16.data_ptr(), x16.data_ptr(),
                      x16.data_ptr(), x16.data_ptr(), x16.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------
+# rcdm_rowchain: tok = a W_a^T + b_a (+ res); y = LayerNorm(tok) (+ pe); tail GEMM (q / qkv) or feed-forward
+
+def _chain_weights(C, tail, frames, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = dict(wa=h16(torch.randn(C, C, generator=g) * C ** -0.5), ba=0.1 * torch.randn(C, generator=g),
+             ln_g=1.0 + 0.2 * torch.randn(C, generator=g), ln_b=0.1 * torch.randn(C, generator=g),
+             pe=(0.3 * torch.randn(frames, C, generator=g)) if frames else None)
+    if tail:
+        w["wt"] = h16(torch.randn(tail * C, C, generator=g) * C ** -0.5)
+    else:
+        w.update(w1=h16(torch.randn(8 * C, C, generator=g) * C ** -0.5), b1=0.1 * torch.randn(8 * C, generator=g),
+                 w2=h16(torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5), b2=0.1 * torch.randn(C, generator=g))
+    return w, g
+
+
+def _chain_reference(a, res, w, tail, rpf):
+    C = a.shape[1]
+    tok = F.linear(a, w["wa"], w["ba"])
+    if res is not None:
+        tok = tok + res
+    tok = h16(tok)                                         # the token rows are stored (and chained) as f16
+    y = F.layer_norm(tok, (C,), w["ln_g"], w["ln_b"], 1e-5)
+    if w["pe"] is not None:
+        frames = w["pe"].shape[0]
+        y = y + w["pe"][(torch.arange(a.shape[0]) // rpf) % frames]
+    y = h16(y)
+    if tail:
+        return tok, F.linear(y, w["wt"])
+    hidden, gate = F.linear(y, w["w1"], w["b1"]).chunk(2, dim=-1)
+    return tok, tok + F.linear(h16(hidden * F.gelu(gate)), w["w2"], w["b2"])
+
+
+def _run_chain(a16, res16, w, tail, M, rpf, in_place_tok=False):
+    from rcdms_amd import hip
+    C = w["ln_g"].numel()
+    dev = {k: (v.to(DEV).contiguous() if v is not None else None) for k, v in w.items()}
+    ws = torch.empty(hip.rowchain_stream_bytes(C, tail), dtype=torch.uint8, device=DEV)
+    b1p = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+    hip.pack_rowchain(dev["wa"].data_ptr(), C, tail, dev["wt"].data_ptr() if tail else 0,
+                      0 if tail else dev["w1"].data_ptr(), 0 if tail else dev["b1"].data_ptr(),
+                      0 if tail else dev["w2"].data_ptr(), ws.data_ptr(), 0 if tail else b1p.data_ptr())
+    ncol = tail * C if tail else C
+    tok = res16 if in_place_tok else torch.full((M + 4, C + 8), 3.0, dtype=torch.float16, device=DEV)
+    out = torch.full((M + 4, ncol + 8), 5.0, dtype=torch.float16, device=DEV)
+    frames = w["pe"].shape[0] if w["pe"] is not None else 1
+    d = hip.RowChainDesc(M, C, a16.stride(0), res16.stride(0) if res16 is not None else 0, tok.stride(0), out.stride(0), tail,
+                         rpf, frames, 1e-5)
+    hip.rowchain(d, a16.data_ptr(), res16.data_ptr() if res16 is not None else 0, tok.data_ptr(), dev["ba"].data_ptr(),
+                 dev["ln_g"].data_ptr(), dev["ln_b"].data_ptr(), dev["pe"].data_ptr() if dev["pe"] is not None else 0,
+                 ws.data_ptr(), 0 if tail else b1p.data_ptr(), 0 if tail else dev["b2"].data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    return tok, out, ncol
+
+
+@pytest.mark.parametrize("tail,has_res,frames,M", [
+    (3, False, 0, 320),     # proj_in -> norm1 -> qkv (spatial)
+    (3, False, 5, 640),     # proj_in -> norms[0] + pe -> qkv (motion; rows_per_frame 64: frames change inside a block)
+    (3, True, 5, 333),      # to_out + res -> norms[1] + pe -> qkv, ragged tail
+    (1, True, 0, 480),      # attn1.to_out + res -> norm2 -> attn2.to_q
+    (0, True, 0, 352),      # attn2.to_out + res -> norm3 -> ff -> + res
+    (0, False, 0, 160),
+])
+def test_rowchain_vs_reference(hiplib, tail, has_res, frames, M):
+    from rcdms_amd import hip
+    C, rpf = 320, 64
+    assert hip.rowchain_supported(C)
+    w, g = _chain_weights(C, tail, frames, 100 + 7 * tail + M)
+    a = h16(torch.randn(M, C, generator=g))
+    res = h16(torch.randn(M, C, generator=g) * 1.5) if has_res else None
+    tok_ref, out_ref = _chain_reference(a, res, w, tail, rpf)
+    a16 = a.half().to(DEV)
+    res16 = res.half().to(DEV) if has_res else None
+    tok, out, ncol = _run_chain(a16, res16, w, tail, M, rpf)
+    close(tok[:M, :C], tok_ref)
+    close(out[:M, :ncol], out_ref)
+    assert (tok[M:] == 3.0).all() and (tok[:, C:] == 3.0).all(), "token stores outside M x C"
+    assert (out[M:] == 5.0).all() and (out[:, ncol:] == 5.0).all(), "tail stores outside the result"
+
+
+def test_rowchain_in_place_token_rows(hiplib):
+    """tok aliasing res (how the engine updates the residual stream), feed-forward tail written over tok as well."""
+    M, C = 800, 320
+    w, g = _chain_weights(C, 0, 0, 77)
+    a = h16(torch.randn(M, C, generator=g))
+    res = h16(torch.randn(M, C, generator=g))
+    tok_ref, out_ref = _chain_reference(a, res, w, 0, 1)
+    from rcdms_amd import hip
+    dev = {k: (v.to(DEV).contiguous() if v is not None else None) for k, v in w.items()}
+    ws = torch.empty(hip.rowchain_stream_bytes(C, 0), dtype=torch.uint8, device=DEV)
+    b1p = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+    hip.pack_rowchain(dev["wa"].data_ptr(), C, 0, 0, dev["w1"].data_ptr(), dev["b1"].data_ptr(), dev["w2"].data_ptr(),
+                      ws.data_ptr(), b1p.data_ptr())
+    tokb = res.half().to(DEV)
+    a16 = a.half().to(DEV)
+    d = hip.RowChainDesc(M, C, C, C, C, C, 0, 1, 1, 1e-5)
+    hip.rowchain(d, a16.data_ptr(), tokb.data_ptr(), tokb.data_ptr(), dev["ba"].data_ptr(), dev["ln_g"].data_ptr(),
+                 dev["ln_b"].data_ptr(), 0, ws.data_ptr(), b1p.data_ptr(), dev["b2"].data_ptr(), tokb.data_ptr())
+    torch.cuda.synchronize()
+    close(tokb, out_ref)

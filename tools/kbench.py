@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of single librcdm_hip kernels at the UNet's hot shapes (HIP-event timed, interleaved rounds).
-usage: python tools/kbench.py [gemm|conv|attn|norm|ff|all] [--variants 0,1,2] [--rounds 5]"""
+usage: python tools/kbench.py [gemm|conv|attn|norm|ff|chain|all] [--variants 0,1,2] [--rounds 5]"""
 import argparse
 import os
 import sys
@@ -245,13 +245,61 @@ def bench_ff(rounds, only=""):
             b1p = torch.empty(8 * C, dtype=torch.float32, device=DEV)
             hip.pack_ff_stream(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), C, wsr.data_ptr(), b1p.data_ptr())
             fd = hip.FFDesc(M, C, C, C, 1e-5)
-            for fv in (0, 1):
-                hip.set_ff_variant(fv)
-                med2, mn2 = timeit(lambda: hip.ff_fused(fd, x.data_ptr(), g.data_ptr(), b.data_ptr(), wsr.data_ptr(), b1p.data_ptr(),
-                                                        b2.data_ptr(), y.data_ptr()), rounds)
-                line += f" | fused v{fv} {med2:7.1f}us (min {mn2:.1f}) {fl / med2 / 1e6:6.0f}TF"
-            hip.set_ff_variant(-1)
+            med2, mn2 = timeit(lambda: hip.ff_fused(fd, x.data_ptr(), g.data_ptr(), b.data_ptr(), wsr.data_ptr(), b1p.data_ptr(),
+                                                    b2.data_ptr(), y.data_ptr()), rounds)
+            line += f" | rcdm_ff_fused {med2:7.1f}us (min {mn2:.1f}) {fl / med2 / 1e6:6.0f}TF"
         print(line, flush=True)
+
+
+def bench_chain(rounds, only=""):
+    """C x C GEMM (+bias +residual) -> LayerNorm (+pe) -> q | k | v GEMM: the three-launch chain vs rcdm_rowchain."""
+    for name, M, C, tail in [("L0 o+res -> LN -> qkv", 40960, 320, 3), ("L0 o+res -> LN -> q", 40960, 320, 1),
+                             ("L0 o+res -> LN -> FF", 40960, 320, 0)]:
+        if only and only not in name:
+            continue
+        a = torch.randn(M, C, device=DEV).half()
+        tok = torch.randn(M, C, device=DEV).half()
+        wa = torch.randn(C, C, device=DEV) * C ** -0.5
+        ba, g, b = torch.randn(C, device=DEV), torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+        pe = torch.randn(5, C, device=DEV)
+        ncol = tail * C if tail else C
+        wt = torch.randn(max(tail, 1) * C, C, device=DEV) * C ** -0.5
+        w1, b1 = torch.randn(8 * C, C, device=DEV) * C ** -0.5, torch.randn(8 * C, device=DEV)
+        w2, b2 = torch.randn(C, 4 * C, device=DEV) * (4 * C) ** -0.5, torch.randn(C, device=DEV)
+        y = torch.empty(M, C, device=DEV, dtype=torch.float16)
+        out = torch.empty(M, ncol, device=DEV, dtype=torch.float16)
+        hid = torch.empty(M, 4 * C, device=DEV, dtype=torch.float16)
+        wah, wth, w2h = wa.half().contiguous(), wt.half().contiguous(), w2.half().contiguous()
+        wp = torch.empty(8 * C, C, dtype=torch.float16, device=DEV)
+        bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+        hip.pack_geglu_rows(w1.data_ptr(), b1.data_ptr(), 8 * C, C, wp.data_ptr(), bp.data_ptr())
+        d0 = hip.GemmDesc(M, C, C, C, C, C, 5, 1, 0, 1.0, 0)
+        lnd = hip.LayerNormDesc(M, C, C, C, 1e-5, 4096, 5)
+        dt = hip.GemmDesc(M, ncol, C, C, ncol, 0, 0, 1, 0, 1.0, 0)
+        d1 = hip.GemmDesc(M, 8 * C, C, C, 4 * C, 0, 9, 1, 0, 1.0, 0)
+        d2 = hip.GemmDesc(M, C, 4 * C, 4 * C, C, C, 5, 1, 0, 1.0, 0)
+        ws = torch.empty(1 << 24, dtype=torch.uint8, device=DEV)
+
+        def chain():
+            hip.gemm(d0, a.data_ptr(), wah.data_ptr(), ba.data_ptr(), 0, tok.data_ptr(), tok.data_ptr(), ws.data_ptr(), ws.numel())
+            hip.layernorm(lnd, tok.data_ptr(), g.data_ptr(), b.data_ptr(), pe.data_ptr(), y.data_ptr())
+            if tail:
+                hip.gemm(dt, y.data_ptr(), wth.data_ptr(), 0, 0, 0, out.data_ptr(), ws.data_ptr(), ws.numel())
+            else:
+                hip.gemm(d1, y.data_ptr(), wp.data_ptr(), bp.data_ptr(), 0, 0, hid.data_ptr(), ws.data_ptr(), ws.numel())
+                hip.gemm(d2, hid.data_ptr(), w2h.data_ptr(), b2.data_ptr(), 0, tok.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel())
+        fl = 2.0 * M * C * C * (1 + (tail if tail else 12))
+        med, mn = timeit(chain, rounds)
+        wsr = torch.empty(hip.rowchain_stream_bytes(C, tail), dtype=torch.uint8, device=DEV)
+        b1p = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+        hip.pack_rowchain(wa.data_ptr(), C, tail, wt.data_ptr() if tail else 0, 0 if tail else w1.data_ptr(),
+                          0 if tail else b1.data_ptr(), 0 if tail else w2.data_ptr(), wsr.data_ptr(), 0 if tail else b1p.data_ptr())
+        rd = hip.RowChainDesc(M, C, C, C, C, ncol, tail, 4096, 5, 1e-5)
+        med2, mn2 = timeit(lambda: hip.rowchain(rd, a.data_ptr(), tok.data_ptr(), tok.data_ptr(), ba.data_ptr(), g.data_ptr(),
+                                                b.data_ptr(), pe.data_ptr(), wsr.data_ptr(), 0 if tail else b1p.data_ptr(),
+                                                0 if tail else b2.data_ptr(), out.data_ptr()), rounds)
+        print(f"chain {name:27s} {fl / 1e9:8.1f} GF | launches {med:7.1f}us {fl / med / 1e6:6.0f}TF | rcdm_rowchain {med2:7.1f}us "
+              f"(min {mn2:.1f}) {fl / med2 / 1e6:6.0f}TF", flush=True)
 
 
 if __name__ == "__main__":
@@ -277,3 +325,5 @@ if __name__ == "__main__":
         bench_norm(a.rounds, a.only)
     if a.what in ("ff", "all"):
         bench_ff(a.rounds, a.only)
+    if a.what in ("chain", "all"):
+        bench_chain(a.rounds, a.only)
