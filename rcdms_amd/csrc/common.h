@@ -31,6 +31,16 @@ static inline int rcdm_check_launch() {
   return RCDM_OK;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: a process that drives a second GPU must set it there too.
+// true the first time it is called on the current device for `done` (a benign race: setting it twice is harmless).
+static inline bool rcdm_first_on_device(bool (&done)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (done[dev]) return false;
+  done[dev] = true;
+  return true;
+}
+
 // v_rcp_f32 (1 ulp) instead of an IEEE division: `a / b` and __frcp_rn expand to ~12 VALU ops on gfx950
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact-form (erf) GELU, as diffusers GEGLU.gelu -> F.gelu(approximate="none"): x * Phi(x) with erf by Abramowitz &

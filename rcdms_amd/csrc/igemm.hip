@@ -817,8 +817,8 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   constexpr int LDS_64 = 2 * (64 + 64) * 128;      // 32 KB
   constexpr int LDS_64D = 4 * (64 + 64) * 128;     // 64 KB  (three steps in flight)
   constexpr int LDS_128x64 = 2 * (128 + 64) * 128; // 48 KB
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (rcdm_first_on_device(attr_set)) {
     set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, false>, LDS_128);
     set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2, false>, LDS_256);
     set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2, false>, LDS_64);
@@ -829,7 +829,6 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
     set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2, true>, LDS_64);
     set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4, true>, LDS_64D);
     set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2, true>, LDS_128x64);
-    attr_set = true;
   }
   if (a.splits > 1) {
     const size_t need = (size_t)a.splits * a.M * a.N * sizeof(float);

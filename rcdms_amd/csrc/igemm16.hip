@@ -109,6 +109,9 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rsrcA, (__attribute__((address_space(3))) void*)(sbase + (wave * NP + i) * 1024), 16, vo, 0, 0, 0);
     }
+#if RCDM_I16_ABLATE & 16   // upper bound of a direct-to-VGPR weight operand: no weight DMA after the first stage
+    if (g > 0) return;
+#endif
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int c = c0 + w_c[i];
@@ -174,11 +177,10 @@ constexpr int kLds16 = 2 * (160 + 160) * 128;  // 81920 B >= the 160 x (320 + 16
 
 template <int TAPS>
 int launch16(const IgemmArgs& a, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (rcdm_first_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)igemm16_kernel<TAPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds16);
     (void)hipFuncSetAttribute((const void*)igemm16_kernel<TAPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds16);
-    attr_set = true;
   }
   dim3 grid(a.tilesM * a.tilesN, a.splits);
   if (a.splits > 1)

@@ -356,13 +356,12 @@ constexpr int pp_lds_bytes() {
 template <int TAPS, int FMW, int FNW>
 int launch_pp(const IgemmArgs& a, hipStream_t stream) {
   constexpr int LDS = pp_lds_bytes<FMW, FNW>();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (rcdm_first_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<TAPS, FMW, FNW, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<TAPS, FMW, FNW, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
   }
   dim3 grid(a.tilesM * a.tilesN, a.splits);
   if (a.splits > 1)

@@ -616,11 +616,10 @@ int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float
   if (threads > 1024) return RCDM_ESHAPE;
   const size_t stats_lds = (size_t)(threads + a.CH) * 16 * sizeof(float);
   if (stats_lds > 64 * 1024) {  // C > 4096: beyond the default dynamic-LDS limit
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    if (rcdm_first_on_device(attr_set)) {
       (void)hipFuncSetAttribute((const void*)gn_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+      }
   }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.splits, a.samples), dim3(threads), stats_lds, stream, a);
   rc = rcdm_check_launch();

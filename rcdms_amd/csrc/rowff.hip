@@ -520,15 +520,11 @@ int launch_chain(const RowArgs& a, hipStream_t stream) {
   const int npar = (HAS_A ? C : 0) + 2 * C + (LN_PE ? a.frames * C : 0) + (TAIL == TAIL_FF ? 8 * C : 0);
   const int lds = R * CHB + npar * 4;
   if (lds > 160 * 1024) return RCDM_ESHAPE;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
   static bool attr_set[64] = {};
-  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    if (hipFuncSetAttribute((const void*)row_chain_kernel<C, NW, R, PD, HAS_A, A_RES, LN_PE, TAIL>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return RCDM_ELAUNCH;
-    attr_set[dev] = true;
-  }
+  if (rcdm_first_on_device(attr_set) &&
+      hipFuncSetAttribute((const void*)row_chain_kernel<C, NW, R, PD, HAS_A, A_RES, LN_PE, TAIL>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return RCDM_ELAUNCH;
   const int nblocks = (a.M + NW * 16 - 1) / (NW * 16);
   hipLaunchKernelGGL((row_chain_kernel<C, NW, R, PD, HAS_A, A_RES, LN_PE, TAIL>), dim3(nblocks), dim3(NW * 64), lds, stream, a);
   return rcdm_check_launch();

@@ -111,8 +111,8 @@ class DenoiseLoop:
         self._v = v
 
     def _cur(self):
-        if self._v is None:
-            self._select(False)
+        if self._v is None:   # a program is ~6 GB of packed weights and buffers: never build one as a side effect
+            raise hip.RcdmError("DenoiseLoop: no launch plan selected yet — call load() first")
         return self._v
 
     prog = property(lambda self: self._cur()["prog"])
@@ -168,6 +168,7 @@ class DenoiseLoop:
             if use_graph and self.graph is None:
                 # warm every kernel up once outside capture (lazy function loading), then restore the state
                 lat0 = self.lat.clone()
+                self.step_dev.zero_()   # the warm-up step reads table / coefficient row `step`: keep it inside the tables
                 self._one_step_eager()
                 self.lat.copy_(lat0)
                 self.step_dev.zero_()
@@ -254,6 +255,7 @@ class PriorLoop:
             if use_graph and self.graph is None:
                 self._graph_causal = self.prog.causal
                 lat0 = self.lat.clone()
+                self.step_dev.zero_()   # the warm-up step reads table / coefficient row `step`: keep it inside the tables
                 self._one_step_eager()        # load every kernel once outside capture, then restore the state
                 self.lat.copy_(lat0)
                 self.step_dev.zero_()

@@ -3,18 +3,18 @@
 CrossAttnUpBlock3D :534-680, UpBlock3D :683-777) and the two factories (:13-169).
 
 Here a block is a parameter container with the reference's child names (resnets / attentions /
-motion_modules / downsamplers / upsamplers); the layer order resnet -> transformer -> motion module and the
-skip push/pop are executed by the launch planner (rcdms_amd.engine.UNetProgram), where the skip concat is a
-buffer layout rather than a copy."""
+motion_modules / downsamplers / upsamplers).  Inside UNet3DConditionModel.forward the layer order resnet ->
+transformer -> motion module and the skip push/pop are executed by the launch planner
+(rcdms_amd.engine.UNetProgram), where the skip concat is a buffer layout rather than a copy.  Called on its own, a
+block's forward() has the reference's signature and return convention and runs its children's HIP forwards one after
+the other (ResnetBlock3D / Transformer3DModel / VanillaTemporalModule / Downsample3D / Upsample3D): correct, not fast —
+the fast path is the UNet's plan."""
+import torch
 from torch import nn
 
 from .attention import Transformer3DModel
 from .motion_module import get_motion_module
 from .resnet import Downsample3D, ResnetBlock3D, Upsample3D
-
-_FUSED = "3-D blocks execute inside UNet3DConditionModel.forward on the HIP path; call the UNet, or the " \
-         "ResnetBlock3D / Transformer3DModel / VanillaTemporalModule children directly"
-
 
 class _Block3D(nn.Module):
     """Shared construction: n layers of [resnet, optional transformer, optional motion module] + sampler."""
@@ -39,8 +39,20 @@ class _Block3D(nn.Module):
             if use_motion_module else None for _ in range(n_motion)])
         self.gradient_checkpointing = False
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(_FUSED)
+    def _layer(self, j, h, temb, encoder_hidden_states, resnet=None):
+        """One [resnet -> transformer -> motion module] layer (reference :412-417, :522-525, :665-670, :768-772)."""
+        h = (resnet if resnet is not None else self.resnets[j])(h, temb)
+        if self.has_cross_attention:
+            h = self.attentions[j](h, encoder_hidden_states=encoder_hidden_states).sample
+        motion = self.motion_modules[j] if j < len(self.motion_modules) else None
+        if motion is not None:
+            h = motion(h, temb, encoder_hidden_states=encoder_hidden_states)
+        return h
+
+    @staticmethod
+    def _no_mask(attention_mask):
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is never passed by the stage-2 pipeline and has no HIP path")
 
 
 def _xf(use_linear_projection, upcast_attention, cfa, ta, only_cross_attention=None):
@@ -75,6 +87,17 @@ class UNetMidBlock3DCrossAttn(_Block3D):
                     xf_kwargs=_xf(use_linear_projection, upcast_attention, unet_use_cross_frame_attention,
                                   unet_use_temporal_attention), n_attn=num_layers, n_motion=num_layers)
 
+    def forward(self, hidden_states, temb=None, encoder_hidden_states=None, attention_mask=None):
+        """reference :272-280: resnets[0], then per layer transformer -> motion module -> resnet."""
+        self._no_mask(attention_mask)
+        h = self.resnets[0](hidden_states, temb)
+        for j, attn in enumerate(self.attentions):
+            h = attn(h, encoder_hidden_states=encoder_hidden_states).sample
+            if self.motion_modules[j] is not None:
+                h = self.motion_modules[j](h, temb, encoder_hidden_states=encoder_hidden_states)
+            h = self.resnets[j + 1](h, temb)
+        return h
+
 
 class _DownBase(_Block3D):
     def _down(self, in_channels, out_channels, temb_channels, num_layers, add_downsample, downsample_padding, **kw):
@@ -82,6 +105,20 @@ class _DownBase(_Block3D):
         self._build(io, temb_channels, **kw)
         self.downsamplers = nn.ModuleList([Downsample3D(out_channels, use_conv=True, out_channels=out_channels,
                                                         padding=downsample_padding, name="op")]) if add_downsample else None
+
+    def forward(self, hidden_states, temb=None, encoder_hidden_states=None, attention_mask=None):
+        """reference :384-427 / :499-531: returns (hidden_states, output_states) — one skip tensor per layer and one
+        after the downsampler."""
+        self._no_mask(attention_mask)
+        h, skips = hidden_states, ()
+        for j in range(len(self.resnets)):
+            h = self._layer(j, h, temb, encoder_hidden_states)
+            skips += (h,)
+        if self.downsamplers is not None:
+            for d in self.downsamplers:
+                h = d(h)
+            skips += (h,)
+        return h, skips
 
 
 class CrossAttnDownBlock3D(_DownBase):
@@ -134,6 +171,20 @@ class _UpBase(_Block3D):
         self._build(io, temb_channels, **kw)
         self.upsamplers = nn.ModuleList([Upsample3D(out_channels, use_conv=True, out_channels=out_channels)]) \
             if add_upsample else None
+
+    def forward(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None, upsample_size=None,
+                attention_mask=None):
+        """reference :631-680 / :748-777: every layer pops the LAST skip tensor and concatenates it behind the hidden
+        states on the channel axis, then resnet -> transformer -> motion module; the upsampler closes the block."""
+        self._no_mask(attention_mask)
+        h, skips = hidden_states, tuple(res_hidden_states_tuple)
+        for j in range(len(self.resnets)):
+            h = self._layer(j, torch.cat([h, skips[-1]], dim=1), temb, encoder_hidden_states)
+            skips = skips[:-1]
+        if self.upsamplers is not None:
+            for u in self.upsamplers:
+                h = u(h, upsample_size)
+        return h
 
 
 class CrossAttnUpBlock3D(_UpBase):

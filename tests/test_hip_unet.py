@@ -196,6 +196,32 @@ def test_full_width_loop_vs_reference_trajectory(full_unet, hw, steps):
         assert r <= LOOP_TOL[hw]["step"], f"step {k}->{k + 1}: {r:.3e}"
 
 
+def test_full_width_loop_flintstones_batch4_vs_alone(full_unet):
+    """BASELINE config 3 THROUGH THE LOOP: 4 FlintstonesSV stories (b = 8 with CFG, L = 91) at 64x64 latents, 3 steps of
+    the 50-step schedule from the captured graph; every checked story of the batch must reproduce the same story run
+    alone (S = 1) — stories never interact; tile shapes differ with M, so not bitwise."""
+    from rcdms_amd.sampler import DenoiseLoop
+    from rcdms_amd.scheduler import DDIMScheduler
+    s = synth.synthetic_story(stories=4, latent_hw=(64, 64), ctx_len=91, seed=44)
+
+    def loop_for(S):
+        sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+        return DenoiseLoop(full_unet, S, 5, 64, 64, 91, 2.0, sched, 50)
+    big = loop_for(4)
+    big.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+    yb = big.run(steps=3).clone().float().cpu()
+    assert yb.shape == (4, 4, 5, 64, 64) and torch.isfinite(yb).all()
+    one = loop_for(1)
+    ctx = s["ctx"].view(8, 5, 91, 768)
+    for i in (1, 3):
+        rows = [i, 4 + i]
+        one.load(s["latents"][i:i + 1], s["mask"][rows], s["masked_latents"][rows], ctx[rows].reshape(10, 91, 768).contiguous())
+        yi = one.run(steps=3).clone().float().cpu()
+        r = rel_rms(yb[i:i + 1], yi)
+        print(f"config-3 loop, story {i}: batch of 4 vs alone after 3 steps rel-RMS {r:.2e}")
+        assert r <= 1.0e-3, f"story {i}: {r:.3e}"   # measured 4.5e-4
+
+
 def _tiny_story(S, cfg=True, seed=3):
     return synth.synthetic_story(stories=S, latent_hw=(16, 16), ctx_len=13, ctx_dim=64, cfg=cfg, seed=seed)
 

@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Per-op timing of one UNet call at the bench workload, aggregated by (kind, shape): every op of the launch plan is
 run alone `--iters` times between HIP events (eager, same buffers), so the numbers include launch gaps the graph hides;
-use them for RELATIVE weight per shape.  usage: python tools/opprof.py [--latent 64] [--iters 5] [--top 60]"""
+use them for RELATIVE weight per shape.  Next to every op INSTANCE: its algorithmic work per step (GFLOP for the
+contractions — 2 MAC, the convention of SURVEY §8(d) — or MB for the HBM-bound norms / temporal attention), and the rate
+that follows, so that every per-kernel fraction quoted in DESIGN.md can be recomputed from the committed table.
+usage: python tools/opprof.py [--latent 64] [--iters 5] [--top 60]"""
+import re
 import argparse
 import collections
 import os
@@ -11,6 +15,39 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def algorithmic_work(tag):
+    """(GFLOP, MB) of ONE launch of the op named by a plan tag (engine.py emitters); None where not applicable."""
+    kv = {k: float(v) for k, v in re.findall(r"(\w+)=(-?[\d.]+)", tag)}
+    kind = tag.split()[0]
+    if kind == "gemm":
+        return 2e-9 * kv["M"] * kv["N"] * kv["K"], None
+    if kind == "gemm_ln":
+        return 2e-9 * kv["M"] * kv["N"] * kv["K"], None
+    if kind == "conv3x3":
+        n, H, W = (float(v) for v in re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
+        cin, cout = (float(v) for v in re.search(r"(\d+)->(\d+)", tag).groups())
+        rows = n * H * W * (4.0 if kv.get("up") else 1.0) / (kv.get("s", 1.0) ** 2)
+        return 2e-9 * rows * 9 * cin * cout, None
+    if kind in ("flash_attn", "xattn", "flash_attn_masked"):
+        Lk = kv.get("Lk", kv.get("L", 0))
+        Lq = kv.get("Lq", kv.get("L", 0))
+        return 4e-9 * kv["B"] * kv["H"] * Lq * Lk * kv["d"], None
+    if kind == "ff_fused":
+        return 2e-9 * kv["M"] * 12 * kv["C"] ** 2, 4e-6 * kv["M"] * kv["C"]
+    if kind == "rowchain":
+        t = kv["tail"]
+        return 2e-9 * kv["M"] * kv["C"] ** 2 * (1 + (t if t else 12)), 2e-6 * kv["M"] * kv["C"] * (2 + kv["res"] + (t if t else 2))
+    if kind == "temporal_attn":
+        C = kv["H"] * kv["d"]
+        rows = kv["S"] * kv["F"] * kv["P"]
+        return 4e-9 * rows * kv["F"] * C, 8e-6 * rows * C
+    if kind == "groupnorm":
+        return None, 6e-6 * kv["S"] * kv["R"] * kv["C"]
+    if kind == "layernorm":
+        return None, 4e-6 * kv["M"] * kv["C"]
+    return None, None
 
 
 def main():
@@ -46,9 +83,15 @@ def main():
             r[0] += 1
             r[1] += e0.elapsed_time(e1) / a.iters * 1e3
     tot = sum(v[1] for v in agg.values())
-    print(f"total {tot / 1e3:.3f} ms over {len(plan.ops)} ops")
+    gf_tot = sum(n * (algorithmic_work(tag)[0] or 0.0) for tag, (n, _) in agg.items())
+    print(f"total {tot / 1e3:.3f} ms over {len(plan.ops)} ops; algorithmic work of the listed contractions {gf_tot / 1e3:.3f} TFLOP per step")
+    print(f"{'ms/step':>8s} {'%':>6s} {'n':>5s} {'avg us':>9s} {'GFLOP/op':>9s} {'TFLOP/s':>8s} {'MB/op':>8s} {'TB/s':>6s}  op")
     for tag, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
-        print(f"{us / 1e3:8.3f} ms {100 * us / tot:5.1f}%  n={n:4d} avg={us / n:8.1f} us  {tag}")
+        gf, mb = algorithmic_work(tag)
+        avg = us / n
+        c1 = f"{gf:9.2f} {gf / avg * 1e-3:8.0f}" if gf else f"{'':9s} {'':8s}"
+        c2 = f"{mb:8.1f} {mb / avg:6.2f}" if mb else f"{'':8s} {'':6s}"
+        print(f"{us / 1e3:8.3f} {100 * us / tot:5.1f}% {n:5d} {avg:9.1f} {c1} {c2}  {tag}")
 
 
 if __name__ == "__main__":
