@@ -59,8 +59,20 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // NW waves per block (4: two blocks per CU; 8: one block of 256 queries per CU — every K/V tile is fetched from L2 and
 // staged once per 256 queries instead of once per 128: the self-attention of the 64x64 level re-reads 640 KB of K/V per
 // query block, 1.6 GB per launch through the ~13 TB/s L2 -> CU path).
-template <int DS, int QF, bool PIPE, bool MASKED, int NW>  // d padded to 16*DS for QK^T and to 32*DF for PV; a wave owns QF fragments of 32 queries
+// MSUB (round 3; needs a spare QK^T column, d < 16 DS: the d = 40 self-attention of the 64x64 level, 85 % of the flash
+// time): the softmax argument comes out of the MATRIX pipe.  Q is pre-multiplied by scale * log2(e), the spare column d
+// of K holds 1 and the same column of Q holds -m (the running max, f16-exact), so the QK^T accumulator IS
+// s * c - m and a score costs v_exp_f32 + half a v_cvt_pkrtz + half a v_max3 instead of those plus an fma.  The scores
+// of tile kt + 1 are issued before the softmax of tile kt has decided its max, so they carry the max of one step earlier:
+// the (per query, usually zero) difference is added only in tiles where some query's max moved — and it moves rarely,
+// because the running max is only raised when a tile exceeds it by more than 2^MSUB_THR (deferred rescale: P <= 64 in
+// f16, row sums and O in fp32).  Whatever value of m is used cancels in O / l, its f16 rounding included.
+constexpr float MSUB_THR = 6.0f;
+
+template <int DS, int QF, bool PIPE, bool MASKED, int NW, int MD = 0>  // MD: MSUB with head dim MD (0: off); d padded to 16*DS for QK^T and to 32*DF for PV; a wave owns QF fragments of 32 queries
 __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p) {
+  constexpr bool MSUB = MD > 0;
+  static_assert(!MSUB || (PIPE && !MASKED && MD < 16 * DS), "MSUB: pipelined, unmasked kernel with a spare QK^T column only");
   constexpr int DF = (DS + 1) / 2;
   constexpr int KP = 16 * DS + 8;  // halfs per K row
   constexpr int NT = NW * 64;
@@ -96,6 +108,8 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p
   for (int i = t; i < (2 * SK + 2 * SV) / 8; i += NT) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   if (ones_row && t < 2 * KT) sV[(t >> 6) * SV + (t & 63) * VR + p.d] = (f16)1.0f;
+  if (MSUB && t < 2 * KT) sK[(t >> 6) * SK + (t & 63) * KP + p.d] = (f16)1.0f;   // K column d := 1 (never restaged: dch chunks only)
+  constexpr int sd_frag = MD >> 4, sd_hi = (MD >> 3) & 1, sd_e = MD & 7;           // where column d sits in a Q fragment
 
   f16x8 qf[QF][DS];
 #pragma unroll
@@ -107,8 +121,15 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p
       v.u = make_uint4(0, 0, 0, 0);
       if (q0 + 32 * j < p.Lq && dc < p.d)
         v.u = *(const uint4*)(p.Q + ((size_t)b * p.Lq + q0 + 32 * j) * p.ldq + h * p.d + dc);
+      if (MSUB) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.e[e] = (f16)((float)v.e[e] * p.c);
+      }
       qf[j][s] = v.h;
     }
+  float m_sub[QF], m_issue[QF];   // MSUB: the max inside the Q fragment now / when the scores being consumed were issued
+#pragma unroll
+  for (int j = 0; j < QF; ++j) m_sub[j] = m_issue[j] = 0.f;
 
   f32x16 oacc[QF][DF];
   float m_run[QF], l_run[QF];
@@ -219,6 +240,9 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p
     put_v(par ^ 1);   // V(kt+1): image `par^1` held V(kt-1), last read in iteration kt-1
     fetch_k();        // K(kt+3)
     fetch_v();        // V(kt+2)
+    float m_next[QF];
+#pragma unroll
+    for (int j = 0; j < QF; ++j) m_next[j] = m_sub[j];
     if constexpr (PIPE) {
       if (kt + 1 < ntiles) qk(par ^ 1, snext);
     } else {
@@ -260,6 +284,48 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p
       for (int r = 1; r < 15; r += 2) mx = max3f(mx, sacc[j][1][r], sacc[j][1][r + 1]);
       mx = fmaxf(mx, sacc[j][1][15]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if constexpr (MSUB) {
+        const float cand = mx + m_issue[j];   // this tile's (scaled) row max
+        float m_new = m_run[j];
+        if (cand > m_run[j] + MSUB_THR) m_new = (float)(f16)cand;   // first tile: m_run = -inf
+        const bool moved = m_new != m_run[j];
+        const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+        m_run[j] = m_new;
+        const float delta = m_issue[j] - m_new;   // the scores carry -m_issue
+        if (__any(delta != 0.f)) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const auto pk = __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(sacc[j][f][r] + delta),
+                                                         __builtin_amdgcn_exp2f(sacc[j][f][r + 1] + delta));
+              pf[j][f * 2 + (r >> 3)][r & 7] = (f16)pk[0];
+              pf[j][f * 2 + (r >> 3)][(r & 7) + 1] = (f16)pk[1];
+            }
+        } else {
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const auto pk = __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(sacc[j][f][r]),
+                                                         __builtin_amdgcn_exp2f(sacc[j][f][r + 1]));
+              pf[j][f * 2 + (r >> 3)][r & 7] = (f16)pk[0];
+              pf[j][f * 2 + (r >> 3)][(r & 7) + 1] = (f16)pk[1];
+            }
+        }
+        if (__any(moved)) {
+          l_run[j] *= alpha;
+#pragma unroll
+          for (int f = 0; f < DF; ++f)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[j][f][e] *= alpha;
+          // the new max into column d of this query's Q fragment (lanes of the half that holds it)
+          m_sub[j] = m_new;
+          if (hi == sd_hi) qf[j][sd_frag < DS ? sd_frag : 0][sd_e] = (f16)(-m_new);
+        }
+        m_issue[j] = m_next[j];
+        continue;
+      }
       float m_new = fmaxf(m_run[j], mx * p.c);  // unmasked: every tile has >= 1 valid key, so m_new is finite
       if constexpr (MASKED) {
         if (m_new == -INFINITY) m_new = 0.f;  // nothing visible to this query so far: P = exp2(-inf - 0) = 0, not NaN
@@ -376,6 +442,20 @@ int launch_flash(const AttnArgs& a_in, hipStream_t stream) {
     hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), false, 8>), grid, dim3(512), lds, stream, a);
   } else {
     dim3 grid(((a.Lq + 127) / 128) * a.heads * a.batch);
+    static int msub_mode = -1;  // RCDM_ATTN_MSUB=0: the fma-based softmax everywhere (A/B switch)
+    if (msub_mode < 0) {
+      const char* e = getenv("RCDM_ATTN_MSUB");
+      msub_mode = e ? atoi(e) : 1;
+    }
+    {
+      // d = 40: a spare QK^T column (40 of 48), a V ones-row (row sums in fp32 out of the PV MFMA) and a long key loop
+      if constexpr (DS == 3) {
+        if (msub_mode && a.d == 40 && a.Lk >= 4 * KT) {
+          hipLaunchKernelGGL((flash_attn_kernel<DS, 1, true, false, 4, 40>), grid, dim3(256), lds, stream, a);
+          return rcdm_check_launch();
+        }
+      }
+    }
     hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), false, 4>), grid, dim3(256), lds, stream, a);
   }
   return rcdm_check_launch();

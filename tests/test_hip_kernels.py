@@ -47,7 +47,7 @@ def rows_to_5d(rows, b, c, f, h, w):
 
 
 def ws(nbytes):
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+    return torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)   # split-K counters (first 16 KiB) start at zero
 
 
 # ------------------------------------------------------------------------------------------------
@@ -541,6 +541,36 @@ def test_flash_attn_forced_rescale(hiplib):
     hip.flash_attn(desc, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr())
     torch.cuda.synchronize()
     close(out.reshape(1, L, C), ref)
+
+
+@pytest.mark.parametrize("L,boost", [(1024, (1.3, 1.8, 2.5, 4.0)), (4096, (1.5, 3.0)), (512, ())])
+def test_flash_attn_deferred_max_long_keys(hiplib, L, boost):
+    """The d = 40 kernel with the softmax argument out of the matrix pipe (MSUB: Q pre-scaled, running max in a spare
+    QK^T column, the max only raised when a tile exceeds it by 2^6): long key loops where the max (a) never moves after the
+    first tile, (b) creeps up by less than the threshold (P > 1 in later tiles), (c) jumps by more in several late tiles —
+    every case against the full fp32 oracle, and bit-identical on a second run."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(31 + L)
+    heads, d = 2, 40
+    C = heads * d
+    q = h16(torch.randn(1, L, C, generator=g))
+    k = h16(torch.randn(1, L, C, generator=g))
+    v = h16(torch.randn(1, L, C, generator=g))
+    for i, f in enumerate(boost):            # growing spikes in later and later key tiles, for a few queries each
+        key = (i + 1) * L // (len(boost) + 1) + 3
+        for qi in (5 + 64 * i, 40 + 64 * i):
+            k[0, key + (qi & 7), :d] = h16(q[0, qi, :d] * f)
+    ref = O.attention_core(q, k, v, heads)
+    qd, kd, vd = (t.reshape(-1, C).half().to(DEV) for t in (q, k, v))
+    desc = hip.AttnDesc(1, heads, L, L, d, C, C, C, C, d ** -0.5)
+    outs = []
+    for _ in range(2):
+        out = torch.empty(L, C, dtype=torch.float16, device=DEV)
+        hip.flash_attn(desc, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        outs.append(out)
+    close(outs[0].reshape(1, L, C), ref)
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("b,frames,pixels,heads,d", [(2, 5, 64, 8, 40), (1, 5, 16, 8, 160), (2, 5, 33, 8, 8), (1, 3, 20, 4, 16)])

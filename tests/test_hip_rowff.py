@@ -80,7 +80,7 @@ def test_ff_fused_in_place_and_vs_unfused_path(hiplib):
     bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
     hip.pack_geglu_rows(dev["w1"].data_ptr(), dev["b1"].data_ptr(), 8 * C, C, wp.data_ptr(), bp.data_ptr())
     hid = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
-    wsb = torch.empty(1 << 24, dtype=torch.uint8, device=DEV)
+    wsb = torch.zeros(1 << 24, dtype=torch.uint8, device=DEV)
     hip.gemm(hip.GemmDesc(M, 8 * C, C, C, 4 * C, 0, hip.EPI_BIAS | hip.EPI_GEGLU, 1, 0, 1.0, 1), a.data_ptr(), wp.data_ptr(),
              bp.data_ptr(), 0, 0, hid.data_ptr(), wsb.data_ptr(), wsb.numel())
     w2h = dev["w2"].half().contiguous()

@@ -89,7 +89,7 @@ def bench_gemm(variants, rounds):
             hip.set_igemm_variant(max(v, -1))
             d = hip.GemmDesc(M, N, K, K, nout, nout, epi, 1, 0, 1.0, SPLIT_K)
             wsb = hip.gemm_workspace_bytes(d)
-            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+            ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=DEV)
             fn = lambda: hip.gemm(d, A.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, res.data_ptr(), out.data_ptr(),
                                   ws.data_ptr(), ws.numel())
             med, mn = timeit(fn, rounds)
@@ -128,7 +128,7 @@ def bench_conv(variants, rounds):
             hip.set_igemm_variant(max(v, -1))
             d = hip.ConvDesc(n, H, W, cin, cout, 1, 0, cin, cout, 0, 1, 1, 0, 1.0, 0)
             wsb = hip.conv3x3_workspace_bytes(d)
-            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+            ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=DEV)
             fn = lambda: hip.conv3x3(d, x.data_ptr(), w.data_ptr(), bias.data_ptr(), 0, 0, out.data_ptr(), ws.data_ptr(),
                                      ws.numel())
             med, mn = timeit(fn, rounds)
@@ -231,7 +231,7 @@ def bench_ff(rounds, only=""):
         lnd = hip.LayerNormDesc(M, C, C, C, 1e-5, 1, 1)
         d1 = hip.GemmDesc(M, 8 * C, C, C, 4 * C, 0, 9, 1, 0, 1.0, 0)
         d2 = hip.GemmDesc(M, C, 4 * C, 4 * C, C, C, 5, 1, 0, 1.0, 0)
-        ws = torch.empty(max(hip.gemm_workspace_bytes(d1), hip.gemm_workspace_bytes(d2), 16), dtype=torch.uint8, device=DEV)
+        ws = torch.zeros(max(hip.gemm_workspace_bytes(d1), hip.gemm_workspace_bytes(d2), 16), dtype=torch.uint8, device=DEV)
 
         def chain():
             hip.layernorm(lnd, x.data_ptr(), g.data_ptr(), b.data_ptr(), 0, a.data_ptr())
@@ -278,7 +278,7 @@ def bench_chain(rounds, only=""):
         dt = hip.GemmDesc(M, ncol, C, C, ncol, 0, 0, 1, 0, 1.0, 0)
         d1 = hip.GemmDesc(M, 8 * C, C, C, 4 * C, 0, 9, 1, 0, 1.0, 0)
         d2 = hip.GemmDesc(M, C, 4 * C, 4 * C, C, C, 5, 1, 0, 1.0, 0)
-        ws = torch.empty(1 << 24, dtype=torch.uint8, device=DEV)
+        ws = torch.zeros(1 << 24, dtype=torch.uint8, device=DEV)
 
         def chain():
             hip.gemm(d0, a.data_ptr(), wah.data_ptr(), ba.data_ptr(), 0, tok.data_ptr(), tok.data_ptr(), ws.data_ptr(), ws.numel())

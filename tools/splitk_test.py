@@ -8,7 +8,7 @@ for name, M, N, K, epi in [("L2 CxC", 2560, 1280, 1280, 5), ("L2 ff-out", 2560, 
     line = name
     for sk in (0, 1, 2, 3, 4, 6, 8):
         d = hip.GemmDesc(M, N, K, K, N, N, epi, 1, 0, 1.0, sk)
-        ws = torch.empty(max(hip.gemm_workspace_bytes(d), 16), dtype=torch.uint8, device="cuda")
+        ws = torch.zeros(max(hip.gemm_workspace_bytes(d), 16), dtype=torch.uint8, device="cuda")
         med, _ = timeit(lambda: hip.gemm(d, A.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, res.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel()))
         line += f" | sk{sk}: {med:6.1f}us"
     print(line)
@@ -20,7 +20,7 @@ for name, n, H, Wd, cin, cout in [("L2 conv 1280", 10, 16, 16, 1280, 1280), ("L2
         line = f"{name} v{v}"
         for sk in (0, 1, 2, 3, 4, 6, 8, 12):
             d = hip.ConvDesc(n, H, Wd, cin, cout, 1, 0, cin, cout, 0, 1, 1, 0, 1.0, sk)
-            ws = torch.empty(max(hip.conv3x3_workspace_bytes(d), 16), dtype=torch.uint8, device="cuda")
+            ws = torch.zeros(max(hip.conv3x3_workspace_bytes(d), 16), dtype=torch.uint8, device="cuda")
             med, _ = timeit(lambda: hip.conv3x3(d, x.data_ptr(), w.data_ptr(), bias.data_ptr(), 0, 0, out.data_ptr(), ws.data_ptr(), ws.numel()))
             line += f" | sk{sk}: {med:6.1f}"
         print(line)
