@@ -670,7 +670,8 @@ int pick_pp(const IgemmArgs& a) {
   if (a.M < 2048 || a.N < 256) return -1;
   if (taps == 1) {
     if (a.M < 20480 || a.N > 1024) return -1;
-    if (!(nk >= 16 || (a.N >= 640 && nk >= 5))) return -1;
+    // (nk 10 / 15: the 1x1 shortcut convs of the 64x64 level, tools/autotune.py + same-box A/B in the graph)
+    if (!(nk >= 10 || (a.N >= 640 && nk >= 5))) return -1;
   } else if (nk < 40) {
     return -1;
   }
@@ -708,7 +709,14 @@ bool pick_16(const IgemmArgs& a) {
   }
   if (!mode) return false;
   const int taps = a.Ktot / a.Cin;
-  if (taps == 1) return a.N >= 960 && a.N >= 2 * a.Cin && a.M >= 2048 && a.Cin <= 1280;  // wide N only: qkv (3C), GEGLU (8C)
+  if (taps == 1) {
+    // plain projections (no epilogue work: the staged halfs are copied out) that split into whole rounds of 160x160 tiles:
+    // the cross-attention queries of the 32x32 level and of the shared-prefix half batch (tools/autotune.py: 17.3 -> 13.8 us)
+    if (a.epi == 0 && a.out_scale == 1.0f && a.M % 160 == 0 && a.N % 160 == 0 && (a.M / 160) * (a.N / 160) >= 256 &&
+        a.Cin <= 640 && a.N <= 640)
+      return true;
+    return a.N >= 960 && a.N >= 3 * a.Cin && a.M >= 2048 && a.Cin <= 1280;  // wide N only: qkv (3C), GEGLU (8C)
+  }
   return a.M >= 5120 && a.M < 20480 && a.N >= 640 && a.N <= 1280;
 }
 
@@ -735,9 +743,12 @@ int pick_variant(const IgemmArgs& a) {
   // blocks per CU keep more DMA in flight; N = 320 / 960 (half a 128-wide tile wasted) with a short K take 128x64;
   // the deep-K convs of the 32x32 / 16x16 levels take 256x256.
   const int nk = (a.Cin + BK - 1) / BK * (a.Ktot / a.Cin);
-  if (a.Ktot != a.Cin) return (a.M >= 2560 && a.M <= 10240 && nk >= 120) ? 2 : 1;
+  if (a.Ktot != a.Cin) {
+    if (a.N <= 64) return 5;  // conv_out (4 -> 8 channels): half the weight tile of 128x128 is padding (51 -> 28 us)
+    return (a.M >= 2560 && a.M <= 10240 && nk >= 120) ? 2 : 1;
+  }
   const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (t128 <= 64 && nk <= 24) return 4;
+  if (t128 <= 64 && nk <= 24) return 4;  // (the two-slot 64x64 ring is 8-10 % faster back to back, tools/autotune.py, but +0.1 ms per step in the graph)
   if (nk >= 20 && nk < 40 && a.N >= 512 && a.M >= 512) {
     // 256x256 (staggered 8-wave loop, ~8 % faster per flop) when its last round of tiles is not emptier than 128x128's
     const int cus = num_cus();
