@@ -89,7 +89,7 @@ def main():
     for tag, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
         gf, mb = algorithmic_work(tag)
         avg = us / n
-        c1 = f"{gf:9.2f} {gf / avg * 1e-3:8.0f}" if gf else f"{'':9s} {'':8s}"
+        c1 = f"{gf:9.2f} {gf / avg * 1e3:8.0f}" if gf else f"{'':9s} {'':8s}"
         c2 = f"{mb:8.1f} {mb / avg:6.2f}" if mb else f"{'':8s} {'':6s}"
         print(f"{us / 1e3:8.3f} {100 * us / tot:5.1f}% {n:5d} {avg:9.1f} {c1} {c2}  {tag}")
 
