@@ -14,7 +14,7 @@ reference's conv/addmm/mm/bmm/baddbmm at b=2,f=5,64x64,L=85) x S / the average r
 events on the launch stream.  The two CFG halves of a step have identical inputs up to the first cross-attention
 (RCDMs_pipeline.py:481-482), so conv_in, the first ResNet block and the first self-attention are evaluated once and
 stored for both (0.21 of the 11.044 TFLOP; exact — config.shared_cfg_prefix, --no-share-prefix for the A/B); `achieved`
-still prices the reference's full 11.044 TFLOP per call.  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
+still prices the reference's full 11.044 TFLOP per call (`roofline.flops_skipped_tflop_per_launch` and `achieved_issued` give the issued-work view).  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
 timed on this box's host cores on a bounded sample (a few UNet calls of the 50), extrapolated to T calls."""
 import argparse
 import contextlib
@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_TFLOP_PER_CALL = {64: 11.044, 32: 2.556}  # per UNet call at b=2 (one story with CFG), L=85  [SURVEY §8d]
+SHARED_PREFIX_TFLOP = {64: 0.208, 32: 0.032}   # per story and call NOT issued under the shared CFG prefix (half of 2 convs 320->320, the first self-attention, 4 C x C / qkv GEMMs)
 MFMA_F16_PEAK_TFLOPS = 2500.0                  # MI355X dense fp16, MI355X_MICROARCH.md
 
 
@@ -318,6 +319,11 @@ def main(argv=None):
                 "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches}
+        # `achieved` prices the REFERENCE's flops per call; what this build does not issue (the CFG halves' identical prefix,
+        # evaluated once) is reported beside it so that the utilisation of the work actually launched can be read off too
+        skipped = SHARED_PREFIX_TFLOP.get(a.latent, 0.0) if loop.shared else 0.0
+        roof["flops_skipped_tflop_per_launch"] = round(skipped * S, 4)
+        roof["achieved_issued"] = round(achieved * (1.0 - skipped / (tf_call * (0.5 if a.cfg_split else 1.0))), 1)
 
     out = {
         "metric": "story-frames/sec (stage-2 UNet, 50-step DDIM, 512^2)", "value": round(value, 4),

@@ -393,8 +393,10 @@ int rcdm_stream_synchronize(void* stream);
  * all-gathered inside the step graph).  Byte-typed, in place on the caller's HIP stream, graph-capturable.
  *   rcdm_comm_unique_id: rank 0 of a group fills 128 bytes, the caller ships them to the other ranks out of band
  *                        (file, socket, torch.distributed object broadcast);
- *   rcdm_comm_create:    collective over the group's ranks (blocks until all have called it);
- *   rcdm_bcast:          `bytes` at `buf` from rank `root` to every rank's `buf`;
+ *   rcdm_comm_create:    collective over the group's ranks (blocks until all have called it); the communicator is bound
+ *                        to the HIP device that is current at this call, and later calls from a thread whose current
+ *                        device differs are refused with RCDM_EINVAL;
+ *   rcdm_bcast:          `bytes` at `buf` from rank `root` (0 <= root < nranks, else RCDM_EINVAL) to every rank's `buf`;
  *   rcdm_allgather:      recv[r * bytes_per_rank ...] on every rank = rank r's send (send may alias its own slot).
  * ---------------------------------------------------------------------------------------------- */
 int rcdm_comm_unique_id(void* id128);

@@ -57,6 +57,13 @@ Rccl& rccl() {
   return r;
 }
 
+// what rcdm_comm_create hands out: the RCCL communicator, its size (root checks) and the device it was bound to
+struct Handle { Comm comm; int nranks; int device; };
+inline bool on_own_device(const Handle* h) {
+  int dev = -1;
+  return hipGetDevice(&dev) == hipSuccess && dev == h->device;
+}
+
 thread_local int g_last_rccl_result = 0;
 inline int rc(int nccl_result) {
   if (nccl_result == 0) return RCDM_OK;
@@ -82,33 +89,41 @@ int rcdm_comm_unique_id(void* id128) {
 
 int rcdm_comm_create(const void* id128, int32_t nranks, int32_t rank, void** comm) {
   if (!id128 || !comm || nranks <= 0 || rank < 0 || rank >= nranks) return RCDM_EINVAL;
+  *comm = nullptr;
   if (!rccl().ok) return RCDM_ECOMM;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return RCDM_ELAUNCH;   // RCCL binds the communicator to the CURRENT device
   UniqueId id;
   memcpy(&id, id128, sizeof id);
   Comm c = nullptr;
   const int r = rc(rccl().comm_init_rank(&c, nranks, id, rank));
-  *comm = r == RCDM_OK ? c : nullptr;
+  if (r == RCDM_OK) *comm = new Handle{c, nranks, dev};
   return r;
 }
 
 int rcdm_comm_destroy(void* comm) {
   if (!comm) return RCDM_EINVAL;
   if (!rccl().ok) return RCDM_ECOMM;
-  return rc(rccl().comm_destroy((Comm)comm));
+  Handle* h = (Handle*)comm;
+  const int r = rc(rccl().comm_destroy(h->comm));
+  delete h;
+  return r;
 }
 
 int rcdm_bcast(void* comm, void* buf, size_t bytes, int32_t root, void* stream) {
-  if (!comm || !buf || root < 0) return RCDM_EINVAL;
+  Handle* h = (Handle*)comm;
+  if (!h || !buf || root < 0 || root >= h->nranks || !on_own_device(h)) return RCDM_EINVAL;
   if (bytes == 0) return RCDM_OK;
   if (!rccl().ok) return RCDM_ECOMM;
-  return rc(rccl().broadcast(buf, buf, bytes, kUint8, root, (Comm)comm, (hipStream_t)stream));
+  return rc(rccl().broadcast(buf, buf, bytes, kUint8, root, h->comm, (hipStream_t)stream));
 }
 
 int rcdm_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
-  if (!comm || !send || !recv) return RCDM_EINVAL;
+  Handle* h = (Handle*)comm;
+  if (!h || !send || !recv || !on_own_device(h)) return RCDM_EINVAL;
   if (bytes_per_rank == 0) return RCDM_OK;
   if (!rccl().ok) return RCDM_ECOMM;
-  return rc(rccl().all_gather(send, recv, bytes_per_rank, kUint8, (Comm)comm, (hipStream_t)stream));
+  return rc(rccl().all_gather(send, recv, bytes_per_rank, kUint8, h->comm, (hipStream_t)stream));
 }
 
 }  // extern "C"

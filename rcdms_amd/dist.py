@@ -132,6 +132,13 @@ class CfgSplit:
         obj.comm = comm
         return obj
 
+    def close(self):
+        """Destroy the pair communicator (both ranks call it, after the DenoiseLoop that captured the exchange is dropped)."""
+        comm = getattr(self, "comm", None)
+        if comm is not None:
+            comm.close()
+            self.comm = None
+
 
 def cfg_split_reference_step(eps_fn, x, ctx_u, ctx_c, half, allgather_tensors):
     """Host restatement of one split step's data flow (CPU tests over gloo): this rank evaluates eps_fn on ITS half

@@ -3,6 +3,7 @@
 fallback: if the library is missing or a call fails this module raises."""
 import ctypes as C
 import os
+import sys
 
 import torch
 
@@ -418,13 +419,16 @@ class Comm:
                                      stream_ptr() if stream is None else stream), "rcdm_allgather")
 
     def close(self):
+        """Destroy the communicator (collective: every rank of it should close).  Call it explicitly, while the peers
+        are alive and after every graph that captured a collective on it is gone."""
         if self.comm:
             load().rcdm_comm_destroy(self.comm)
             self.comm = C.c_void_p(0)
 
     def __del__(self):
+        # never at interpreter teardown: ncclCommDestroy can block on a peer that has already exited
         try:
-            if _lib is not None:
+            if _lib is not None and not sys.is_finalizing():
                 self.close()
         except Exception:
             pass
