@@ -154,6 +154,11 @@ size_t rcdm_groupnorm_workspace_bytes(const rcdm_groupnorm_desc* d);
 int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float* gamma,
                         const float* beta, void* y, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* statistics only: stat[sample][group][2] = (mean, 1 / sqrt(var + eps)), fp32 — the first two launches of the three-launch
+ * form, for a consumer that applies the normalisation itself (rcdm_rowchain's gn_stat: the norm in front of proj_in,
+ * attention.py:328-330, motion_module.py:162-166).  ldy / silu of the descriptor are ignored; workspace as above. */
+int rcdm_groupnorm_stats(const rcdm_groupnorm_desc* d, const void* x, float* stat, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps 1e-5, torch default) with optional fused positional-encoding add
@@ -256,6 +261,10 @@ int rcdm_ff_fused(const rcdm_ff_desc* d, const void* x, const float* ln_gamma, c
  *   W_a = fp32 [C][C] (nn.Linear layout).  The weights come as one fragment-major stream (rcdm_pack_rowchain,
  *   rcdm_rowchain_stream_bytes); b1_packed / b2 only with tail 0.  tok may alias res, out may alias tok (tail 0) — a block
  *   reads and writes only its own rows.  Supported C: rcdm_rowchain_supported.
+ *   gn_stat != NULL (only with res == NULL): a_in is the RAW input of the GroupNorm in front of proj_in and the kernel
+ *   applies  a_in[m][c] * rstd * gn_gamma[c] + (gn_beta[c] - mean * rstd * gn_gamma[c])  (rounded to f16 like the separate
+ *   launch) with (mean, rstd) = gn_stat[m / gn_rows][c / (C / gn_groups)] from rcdm_groupnorm_stats; gn_rows % 16 == 0,
+ *   gn_rows >= 160.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   int32_t M, C;
@@ -263,6 +272,7 @@ typedef struct {
   int32_t tail;                    /* 0 = feed-forward, 1 = GEMM to C columns, 3 = GEMM to 3C columns */
   int32_t rows_per_frame, frames;  /* only with pe */
   float eps;                       /* LayerNorm eps (1e-5) */
+  int32_t gn_groups, gn_rows;      /* only with gn_stat: groups and rows per sample of the GroupNorm */
 } rcdm_rowchain_desc;
 int rcdm_rowchain_supported(int32_t C);
 size_t rcdm_rowchain_stream_bytes(int32_t C, int32_t tail);
@@ -271,7 +281,8 @@ int rcdm_pack_rowchain(const float* wa, int32_t C, int32_t tail, const float* wt
                        const float* w2, void* wstream, float* b1_packed, void* stream);
 int rcdm_rowchain(const rcdm_rowchain_desc* d, const void* a_in, const void* res, void* tok, const float* a_bias,
                   const float* ln_gamma, const float* ln_beta, const float* pe, const void* wstream, const float* b1_packed,
-                  const float* b2, void* out, void* stream);
+                  const float* b2, void* out, const float* gn_stat, const float* gn_gamma, const float* gn_beta,
+                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row softmax: y[m][n] = softmax over n of (scale * x[m][n]); f16 rows, fp32 math, N % 8 == 0, N <= 4096, scale > 0.

@@ -161,7 +161,7 @@ __global__ void gn_apply_kernel(const GnArgs p) {
       const float mean = p.stat[(s * p.G + g) * 2], rstd = p.stat[(s * p.G + g) * 2 + 1];
       const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
       sc[e] = rstd * ga;
-      sh[e] = be - mean * rstd * ga;
+      sh[e] = __builtin_fmaf(-(mean * rstd), ga, be);   // explicit: rowff.hip's prologue form must round the same way
     }
   }
   const f16* xb = p.x + (size_t)s * p.P * p.ldx + ch * 8;
@@ -178,7 +178,7 @@ __global__ void gn_apply_kernel(const GnArgs p) {
       Pack16 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float f = (float)v[u].e[e] * sc[e] + sh[e];
+        float f = __builtin_fmaf((float)v[u].e[e], sc[e], sh[e]);
         if (p.silu) f = silu_f(f);
         o.e[e] = (f16)f;
       }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnFusedArgs p) {
       const float mean = gstat[g * 2], rstd = gstat[g * 2 + 1];
       const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
       sc[e] = rstd * ga;
-      sh[e] = be - mean * rstd * ga;
+      sh[e] = __builtin_fmaf(-(mean * rstd), ga, be);   // explicit: rowff.hip's prologue form must round the same way
     }
   }
   for (int r = rl; r < p.P; r += 4 * p.RPB) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnFusedArgs p) {
       Pack16 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float f = (float)v[u].e[e] * sc[e] + sh[e];
+        float f = __builtin_fmaf((float)v[u].e[e], sc[e], sh[e]);
         if (p.silu) f = silu_f(f);
         o.e[e] = (f16)f;
       }
@@ -633,6 +633,29 @@ int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float
   if (bps > cap) bps = cap;
   if (bps < 1) bps = 1;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(bps, a.samples), dim3(threads), 0, stream, a);
+  return rcdm_check_launch();
+}
+
+int rcdm_groupnorm_stats(const rcdm_groupnorm_desc* d, const void* x, float* stat, void* workspace, size_t workspace_bytes,
+                         void* stream_) {
+  if (!d || !x || !stat) return RCDM_EINVAL;
+  GnArgs a{};
+  int rc = gn_plan(d, a);
+  if (rc) return rc;
+  const size_t need = (size_t)a.samples * a.splits * a.G * 3 * sizeof(float);
+  if (!workspace || workspace_bytes < need) return RCDM_EWORKSPACE;
+  a.x = (const f16*)x;
+  a.partial = (float*)workspace;
+  a.stat = stat;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int threads = a.CH * a.RPB;
+  if (threads > 1024) return RCDM_ESHAPE;
+  const size_t stats_lds = (size_t)(threads + a.CH) * 16 * sizeof(float);
+  if (stats_lds > 64 * 1024) return RCDM_ESHAPE;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.splits, a.samples), dim3(threads), stats_lds, stream, a);
+  rc = rcdm_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((a.samples * a.G + 3) / 4), dim3(256), 0, stream, a);
   return rcdm_check_launch();
 }
 

@@ -61,8 +61,12 @@ struct RowArgs {
   const float* pe;     // [frames][C] (LN_PE)
   const float* b1p;    // [8C] packed (TAIL_FF): per (group, pair) 16 hidden biases then their 16 gate biases
   const float* b2;     // [C] (TAIL_FF)
+  const float* gn_stat; // [samples][gn_G][2] = (mean, rstd) of the GroupNorm whose apply runs in the prologue (HAS_A && !A_RES), or null
+  const float* gn_g;    // [C] GroupNorm weight
+  const float* gn_b;    // [C] GroupNorm bias
   int M, lda, ldr, ldt, ldo;
   int rows_per_frame, frames;
+  int gn_G, gn_rows;    // groups; rows per GroupNorm sample (>= the block's rows: a block meets at most two samples)
   float eps;
 };
 
@@ -92,7 +96,8 @@ __global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
   const int row = row0 + l15;
   const bool live = row < p.M;
   const int oG = HAS_A ? C : 0, oB = oG + C, oPE = oB + C, oT = oPE + (LN_PE ? p.frames * C : 0);
-  const int npar = oT + (TAIL == TAIL_FF ? 8 * C : 0);
+  const int oGN = oT + (TAIL == TAIL_FF ? 8 * C : 0);   // [2 samples][scale C | shift C] of the prologue GroupNorm
+  const int npar = oGN;
 
   const __amdgpu_buffer_rsrc_t rsrcW =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, (unsigned)NCH * CHB, 0x00020000);
@@ -144,6 +149,20 @@ __global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
     else src = p.b1p + (idx - oT);
     bq[i] = *(const f32x4*)src;
   }
+  // GroupNorm apply in the prologue (attention.py:328-330 / motion_module.py:162-166: norm, then proj_in): this block's
+  // rows belong to at most two samples; thread (j, c) prepares scale / shift of channel c for the block's sample j
+  float gn_sc = 0.f, gn_sh = 0.f;
+  constexpr bool CAN_GN = HAS_A && !A_RES;
+  static_assert(NT == 2 * C, "one thread per (sample slot, channel)");
+  if (CAN_GN && p.gn_stat) {
+    const int j = t >= C ? 1 : 0, ch = t - j * C;
+    const int nsamp = (p.M + p.gn_rows - 1) / p.gn_rows;
+    const int smp = min((int)(blockIdx.x * (NW * 16)) / p.gn_rows + j, nsamp - 1);
+    const float* st = p.gn_stat + ((size_t)smp * p.gn_G + ch / (C / p.gn_G)) * 2;
+    const float ga = p.gn_g[ch], be = p.gn_b[ch], mean = st[0], rstd = st[1];
+    gn_sc = rstd * ga;                  // the same expressions as gn_apply_kernel (norm.hip): same roundings
+    gn_sh = __builtin_fmaf(-(mean * rstd), ga, be);
+  }
   int cslot = 0;  // slot of the chunk consumed next
 #pragma unroll
   for (int c = 0; c < R - 1; ++c) issue_chunk(c, c);
@@ -153,9 +172,36 @@ __global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
     if (idx < npar / 4) *(f32x4*)(smem + PAR0 + 16 * idx) = bq[i];
   }
   const float* par = (const float*)(smem + PAR0);
+  if (CAN_GN && p.gn_stat) {
+    float* gp = (float*)(smem + PAR0) + oGN + (t >= C ? 2 * C : 0) + (t >= C ? t - C : t);
+    gp[0] = gn_sc;
+    gp[C] = gn_sh;
+  }
   wait_lgkm0();
   wait_vm<(R - 2) * PPW>();  // this wave's pieces of chunk 0 (the compiler's own wait for the plain loads came earlier)
   tick_barrier();            // the parameters and chunk 0 are in LDS
+
+  if (CAN_GN && p.gn_stat) {
+    // y = f16(x * scale + shift): the arithmetic of gn_apply_kernel (norm.hip), bit-identical to the separate launch
+    const int j = row0 / p.gn_rows - (int)(blockIdx.x * (NW * 16)) / p.gn_rows;   // wave-uniform: gn_rows % 16 == 0
+    const float* gs = par + oGN + (j > 0 ? 2 * C : 0) + 8 * kg;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      const f32x4 c0 = *(const f32x4*)(gs + 32 * s), c1 = *(const f32x4*)(gs + 32 * s + 4);
+      const f32x4 h0 = *(const f32x4*)(gs + C + 32 * s), h1 = *(const f32x4*)(gs + C + 32 * s + 4);
+      f16x8 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // fp32 result first, then its f16 rounding, as the separate launch does: left alone, the compiler merges the two
+        // into v_fma_mixlo_f16 (ONE rounding) and one element in ~20 000 comes out an ulp away from gn_apply's
+        float f0 = __builtin_fmaf((float)xr[s][e], c0[e], h0[e]), f1 = __builtin_fmaf((float)xr[s][4 + e], c1[e], h1[e]);
+        asm volatile("" : "+v"(f0), "+v"(f1));
+        y[e] = (f16)f0;
+        y[4 + e] = (f16)f1;
+      }
+      xr[s] = y;
+    }
+  }
 
   // ---- the weight stream is ONE software pipeline over all NCH * CHF fragments: the read of fragment f + PD is issued
   // with the MFMA of fragment f, across chunk boundaries (no drain at the barriers).  Chunk hand-over at the top of chunk
@@ -518,7 +564,7 @@ int launch_chain(const RowArgs& a, hipStream_t stream) {
   constexpr int C = 320, NW = 10, R = 7, PD = 2;
   constexpr int CHB = 2 * (C / 32) * 1024;
   const int npar = (HAS_A ? C : 0) + 2 * C + (LN_PE ? a.frames * C : 0) + (TAIL == TAIL_FF ? 8 * C : 0);
-  const int lds = R * CHB + npar * 4;
+  const int lds = R * CHB + (npar + (a.gn_stat ? 4 * C : 0)) * 4;
   if (lds > 160 * 1024) return RCDM_ESHAPE;
   static bool attr_set[64] = {};
   if (rcdm_first_on_device(attr_set) &&
@@ -588,7 +634,7 @@ int rcdm_ff_fused(const rcdm_ff_desc* d, const void* x, const float* ln_gamma, c
 
 int rcdm_rowchain(const rcdm_rowchain_desc* d, const void* a_in, const void* res, void* tok, const float* a_bias,
                   const float* ln_gamma, const float* ln_beta, const float* pe, const void* wstream, const float* b1_packed,
-                  const float* b2, void* out, void* stream) {
+                  const float* b2, void* out, const float* gn_stat, const float* gn_gamma, const float* gn_beta, void* stream) {
   if (!d || !a_in || !tok || !a_bias || !ln_gamma || !ln_beta || !wstream || !out) return RCDM_EINVAL;
   const int ncol = d->tail == 0 ? d->C : d->tail * d->C;
   if (d->M <= 0 || d->lda < d->C || d->ldt < d->C || d->ldo < ncol || ((d->lda | d->ldt | d->ldo) & 7)) return RCDM_EINVAL;
@@ -596,11 +642,16 @@ int rcdm_rowchain(const rcdm_rowchain_desc* d, const void* a_in, const void* res
   if (pe && (d->rows_per_frame <= 0 || d->frames <= 0 || d->frames > 8)) return RCDM_EINVAL;
   if (d->tail == 0 && (!b1_packed || !b2)) return RCDM_EINVAL;
   if (d->C != 320 || !(d->tail == 0 || d->tail == 1 || d->tail == 3)) return RCDM_ESHAPE;
+  if (gn_stat) {   // GroupNorm apply on the incoming rows: only the form without a stage-A residual has the operand free
+    if (res || !gn_gamma || !gn_beta || d->gn_groups <= 0 || d->gn_rows <= 0) return RCDM_EINVAL;
+    if (d->C % d->gn_groups || d->gn_rows % 16 || d->gn_rows < 160) return RCDM_ESHAPE;
+  }
   RowArgs a{};
   a.a_in = (const f16*)a_in; a.res = (const f16*)res; a.tok = (f16*)tok; a.out = (f16*)out; a.wstream = (const f16*)wstream;
   a.a_bias = a_bias; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.pe = pe; a.b1p = b1_packed; a.b2 = b2;
   a.M = d->M; a.lda = d->lda; a.ldr = d->ldr; a.ldt = d->ldt; a.ldo = d->ldo;
   a.rows_per_frame = pe ? d->rows_per_frame : 1; a.frames = pe ? d->frames : 1; a.eps = d->eps;
+  a.gn_stat = gn_stat; a.gn_g = gn_gamma; a.gn_b = gn_beta; a.gn_G = d->gn_groups; a.gn_rows = d->gn_rows;
   hipStream_t s = (hipStream_t)stream;
 #define RCDM_CHAIN(T)                                                                  \
   (res ? (pe ? launch_chain<true, true, true, T>(a, s) : launch_chain<true, true, false, T>(a, s)) \

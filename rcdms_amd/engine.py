@@ -175,6 +175,21 @@ def emit_groupnorm(plan, x, samples, rows_per_sample, gamma, beta, eps, silu, ou
     plan.n_launch += 3
 
 
+def emit_groupnorm_stats(plan, x, samples, rows_per_sample, gamma, beta, eps, groups=32):
+    """(mean, rstd) of a GroupNorm only — the consumer (emit_rowchain's `gn`) applies it while loading its rows.
+    Returns the `gn` tuple emit_rowchain takes."""
+    d = hip.GroupNormDesc(samples, rows_per_sample, x.C, groups, x.ld, x.ld, eps, 0)
+    ws = plan.scratch("gn_ws", hip.groupnorm_workspace_bytes(d))
+    stat = plan.scratch("gn_stat", samples * groups * 2 * 4)
+
+    def op():
+        hip.groupnorm_stats(d, x.ptr, stat.ptr, ws.ptr, ws.nbytes)
+    plan.add(op, f"groupnorm_stats S={samples} R={rows_per_sample} C={x.C}")
+    plan.keep += [gamma, beta]
+    plan.n_launch += 2
+    return (stat, gamma, beta, groups, rows_per_sample)
+
+
 def emit_layernorm(plan, x, gamma, beta, out, pe=None, rows_per_frame=1, frames=1):
     lg = getattr(plan, "last_gemm", None)
     plan.last_gemm = None
@@ -500,20 +515,24 @@ FF_FUSE = os.environ.get("RCDM_FF_FUSE", "1") != "0"
 # rcdm_rowchain (rowff.hip): [C x C projection (+ residual) -> LayerNorm (+ pe) -> q | qkv projection or feed-forward] as one
 # row-stationary launch.  RCDM_ROWCHAIN=0 keeps the separate launches (same-process A/B).
 ROW_CHAIN = os.environ.get("RCDM_ROWCHAIN", "1") != "0"
+CHAIN_GN = os.environ.get("RCDM_CHAIN_GN", "1") != "0"   # GroupNorm apply in the prologue of the proj_in chain
 
 
-def emit_rowchain(plan, a_in, res, tok, a_bias, ln, pe, stream, tail, out, rows_per_frame=1, frames=1, b2=None):
+def emit_rowchain(plan, a_in, res, tok, a_bias, ln, pe, stream, tail, out, rows_per_frame=1, frames=1, b2=None, gn=None):
     """tok = a_in W_a^T + a_bias (+ res);  y = LayerNorm(tok) (+ pe);  tail 1 / 3: out = y W_t^T;  tail 0: out = tok + FF(y).
-    ln = (gamma, beta); stream = Packer.chain(...)."""
+    ln = (gamma, beta); stream = Packer.chain(...); gn = emit_groupnorm_stats(...): a_in is the RAW input of that
+    GroupNorm and the kernel applies it while loading its rows (res must be None)."""
     ws, b1p = stream
     M, C = a_in.M, a_in.C
-    d = hip.RowChainDesc(M, C, a_in.ld, res.ld if res is not None else 0, tok.ld, out.ld, tail, rows_per_frame, frames, 1e-5)
+    d = hip.RowChainDesc(M, C, a_in.ld, res.ld if res is not None else 0, tok.ld, out.ld, tail, rows_per_frame, frames, 1e-5,
+                         gn[3] if gn else 0, gn[4] if gn else 0)
 
     def op():
         hip.rowchain(d, a_in.ptr, res.ptr if res is not None else 0, tok.ptr, a_bias.data_ptr(), ln[0].data_ptr(),
                      ln[1].data_ptr(), pe.data_ptr() if pe is not None else 0, ws.data_ptr(),
-                     b1p.data_ptr() if b1p is not None else 0, b2.data_ptr() if b2 is not None else 0, out.ptr)
-    plan.add(op, f"rowchain M={M} C={C} tail={tail} res={int(res is not None)} pe={int(pe is not None)}")
+                     b1p.data_ptr() if b1p is not None else 0, b2.data_ptr() if b2 is not None else 0, out.ptr,
+                     gn_stat=gn[0].ptr if gn else 0, gn_g=gn[1].data_ptr() if gn else 0, gn_b=gn[2].data_ptr() if gn else 0)
+    plan.add(op, f"rowchain M={M} C={C} tail={tail} res={int(res is not None)} pe={int(pe is not None)} gn={int(gn is not None)}")
     plan.keep += [a_bias, ln[0], ln[1], pe, ws, b1p, b2]
     plan.n_launch += 1
     plan.last_gemm = None
@@ -555,7 +574,7 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
     # emitted yet and rides in the chain launch with norm1 and the q | k | v projection
     qkv = plan.rows("qkv", M, 3 * C).rows(0, Ms)
     if pre is not None:
-        emit_rowchain(plan, pre[0], None, tok, pre[1], w.ln[0], None, w.ch_in_qkv, 3, qkv)
+        emit_rowchain(plan, pre[0], None, tok, pre[1], w.ln[0], None, w.ch_in_qkv, 3, qkv, gn=pre[2])
     else:
         emit_layernorm(plan, tok.rows(0, Ms), w.ln[0][0], w.ln[0][1], a.rows(0, Ms))
         emit_gemm(plan, a.rows(0, Ms), w.qkv1, 3 * C, C, qkv, bias=w.qkv1_b)
@@ -595,12 +614,16 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     g, C = geo, w.C
     n_s, M_s = (g.n_img // 2, g.M // 2) if shared_half else (g.n_img, g.M)
     a = plan.rows("norm", g.M, C)
-    emit_groupnorm(plan, x.rows(0, M_s), n_s, g.hw, w.gn_g, w.gn_b, 1e-6, False, a.rows(0, M_s), groups)
     tok = plan.rows("tok", g.M, C)
     pre = None
     if w.ch_in_qkv is not None and not shared_half:
-        pre = (a, w.proj_in_b)       # proj_in rides with norm1 + qkv (emit_basic_block)
+        if CHAIN_GN and g.hw % 16 == 0 and g.hw >= 160:   # the norm's apply rides too: only its statistics are launched
+            pre = (x, w.proj_in_b, emit_groupnorm_stats(plan, x, n_s, g.hw, w.gn_g, w.gn_b, 1e-6, groups))
+        else:
+            emit_groupnorm(plan, x, n_s, g.hw, w.gn_g, w.gn_b, 1e-6, False, a, groups)
+            pre = (a, w.proj_in_b, None)       # proj_in rides with norm1 + qkv (emit_basic_block)
     else:
+        emit_groupnorm(plan, x.rows(0, M_s), n_s, g.hw, w.gn_g, w.gn_b, 1e-6, False, a.rows(0, M_s), groups)
         emit_gemm(plan, a.rows(0, M_s), w.proj_in, C, C, tok.rows(0, M_s), bias=w.proj_in_b)
     emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img, pre=pre)
     emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
@@ -622,17 +645,21 @@ def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
     g, C = geo, w.C
     d_head = C // heads
     a = plan.rows("norm", g.M, C)
+    chained = w.chains is not None and not prior_state
+    gn = None
     if prior_state:
         emit_layernorm(plan, x, w.prior_g, w.prior_b, a)
+    elif chained and CHAIN_GN and g.hw % 16 == 0 and g.hw >= 160:
+        gn = emit_groupnorm_stats(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, groups)
     else:
         emit_groupnorm(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, False, a, groups)
     tok = plan.rows("tok", g.M, C)
-    if w.chains is not None and not prior_state:
+    if chained:
         # three chain launches + two temporal attentions + proj_out instead of twelve launches
         qkv = plan.rows("qkv", g.M, 3 * C)
         ao = plan.rows("attn_out", g.M, C)
         a0, a1 = w.attn
-        emit_rowchain(plan, a, None, tok, w.proj_in_b, (a0.ln_g, a0.ln_b), a0.pe, w.chains[0], 3, qkv, g.hw, g.f)
+        emit_rowchain(plan, x if gn else a, None, tok, w.proj_in_b, (a0.ln_g, a0.ln_b), a0.pe, w.chains[0], 3, qkv, g.hw, g.f, gn=gn)
         emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)
         emit_rowchain(plan, ao, tok, tok, a0.o_b, (a1.ln_g, a1.ln_b), a1.pe, w.chains[1], 3, qkv, g.hw, g.f)
         emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)

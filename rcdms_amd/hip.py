@@ -58,7 +58,7 @@ class FFDesc(C.Structure):
 class RowChainDesc(C.Structure):
     _fields_ = [("M", C.c_int32), ("C", C.c_int32), ("lda", C.c_int32), ("ldr", C.c_int32), ("ldt", C.c_int32),
                 ("ldo", C.c_int32), ("tail", C.c_int32), ("rows_per_frame", C.c_int32), ("frames", C.c_int32),
-                ("eps", C.c_float)]
+                ("eps", C.c_float), ("gn_groups", C.c_int32), ("gn_rows", C.c_int32)]
 
 
 class AttnDesc(C.Structure):
@@ -90,6 +90,7 @@ SYMBOLS = {
     "rcdm_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_groupnorm_workspace_bytes": (_SZ, [C.POINTER(GroupNormDesc)]),
     "rcdm_groupnorm_silu": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _SZ, _P]),
+    "rcdm_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _SZ, _P]),
     "rcdm_softmax_rows": (C.c_int, [_I, _I, _I, _I, C.c_float, _P, _P, _P]),
     "rcdm_layernorm": (C.c_int, [C.POINTER(LayerNormDesc), _P, _P, _P, _P, _P, _P]),
     "rcdm_flash_attn": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
@@ -102,7 +103,7 @@ SYMBOLS = {
     "rcdm_rowchain_supported": (C.c_int, [_I]),
     "rcdm_rowchain_stream_bytes": (_SZ, [_I, _I]),
     "rcdm_pack_rowchain": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "rcdm_rowchain": (C.c_int, [C.POINTER(RowChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rcdm_rowchain": (C.c_int, [C.POINTER(RowChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rcdm_timestep_embed": (C.c_int, [_P, _I, _I, _P, _P]),
     "rcdm_small_linear": (C.c_int, [_P, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "rcdm_assemble_input": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -216,6 +217,11 @@ def groupnorm_silu(desc, x, gamma, beta, y, ws_ptr, ws_bytes, stream=None):
                                       stream_ptr() if stream is None else stream), "rcdm_groupnorm_silu")
 
 
+def groupnorm_stats(desc, x, stat, ws_ptr, ws_bytes, stream=None):
+    _check(load().rcdm_groupnorm_stats(C.byref(desc), x, stat, ws_ptr, ws_bytes,
+                                       stream_ptr() if stream is None else stream), "rcdm_groupnorm_stats")
+
+
 def layernorm(desc, x, gamma, beta, pe, y, stream=None):
     _check(load().rcdm_layernorm(C.byref(desc), x, gamma, beta, pe, y,
                                  stream_ptr() if stream is None else stream), "rcdm_layernorm")
@@ -267,9 +273,10 @@ def pack_rowchain(wa, Cc, tail, wt, w1, b1, w2, wstream, b1p, stream=None):
                                      stream_ptr() if stream is None else stream), "rcdm_pack_rowchain")
 
 
-def rowchain(desc, a_in, res, tok, a_bias, ln_g, ln_b, pe, wstream, b1p, b2, out, stream=None):
+def rowchain(desc, a_in, res, tok, a_bias, ln_g, ln_b, pe, wstream, b1p, b2, out, stream=None, gn_stat=None, gn_g=None,
+             gn_b=None):
     _check(load().rcdm_rowchain(C.byref(desc), a_in, res, tok, a_bias, ln_g, ln_b, pe, wstream, b1p, b2, out,
-                                stream_ptr() if stream is None else stream), "rcdm_rowchain")
+                                gn_stat, gn_g, gn_b, stream_ptr() if stream is None else stream), "rcdm_rowchain")
 
 
 def pack_ff_stream(w1, b1, w2, Cc, wstream, b1p, stream=None):

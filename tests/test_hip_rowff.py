@@ -139,7 +139,7 @@ def _chain_reference(a, res, w, tail, rpf):
     return tok, tok + F.linear(h16(hidden * F.gelu(gate)), w["w2"], w["b2"])
 
 
-def _run_chain(a16, res16, w, tail, M, rpf, in_place_tok=False):
+def _run_chain(a16, res16, w, tail, M, rpf, in_place_tok=False, gn=None):
     from rcdms_amd import hip
     C = w["ln_g"].numel()
     dev = {k: (v.to(DEV).contiguous() if v is not None else None) for k, v in w.items()}
@@ -153,10 +153,11 @@ def _run_chain(a16, res16, w, tail, M, rpf, in_place_tok=False):
     out = torch.full((M + 4, ncol + 8), 5.0, dtype=torch.float16, device=DEV)
     frames = w["pe"].shape[0] if w["pe"] is not None else 1
     d = hip.RowChainDesc(M, C, a16.stride(0), res16.stride(0) if res16 is not None else 0, tok.stride(0), out.stride(0), tail,
-                         rpf, frames, 1e-5)
+                         rpf, frames, 1e-5, gn[3] if gn else 0, gn[4] if gn else 0)
     hip.rowchain(d, a16.data_ptr(), res16.data_ptr() if res16 is not None else 0, tok.data_ptr(), dev["ba"].data_ptr(),
                  dev["ln_g"].data_ptr(), dev["ln_b"].data_ptr(), dev["pe"].data_ptr() if dev["pe"] is not None else 0,
-                 ws.data_ptr(), 0 if tail else b1p.data_ptr(), 0 if tail else dev["b2"].data_ptr(), out.data_ptr())
+                 ws.data_ptr(), 0 if tail else b1p.data_ptr(), 0 if tail else dev["b2"].data_ptr(), out.data_ptr(),
+                 gn_stat=gn[0].data_ptr() if gn else 0, gn_g=gn[1].data_ptr() if gn else 0, gn_b=gn[2].data_ptr() if gn else 0)
     torch.cuda.synchronize()
     return tok, out, ncol
 
@@ -206,3 +207,49 @@ def test_rowchain_in_place_token_rows(hiplib):
                  dev["ln_b"].data_ptr(), 0, ws.data_ptr(), b1p.data_ptr(), dev["b2"].data_ptr(), tokb.data_ptr())
     torch.cuda.synchronize()
     close(tokb, out_ref)
+
+
+@pytest.mark.parametrize("frames,rows,samples", [(0, 176, 3), (5, 160, 5), (0, 1024, 2)])
+def test_rowchain_groupnorm_prologue(hiplib, frames, rows, samples):
+    """GroupNorm -> proj_in -> norm -> qkv with the norm's APPLY inside the chain launch (attention.py:328-330,
+    motion_module.py:162-166): against the reference arithmetic, and bit-identical to rcdm_groupnorm_silu followed by the
+    chain without the prologue.  rows = 176: blocks of 160 rows meet two samples, also in the middle of the tensor."""
+    from rcdms_amd import hip
+    C, G, M = 320, 32, rows * samples
+    w, g = _chain_weights(C, 3, frames, 900 + rows)
+    x = h16(torch.randn(M, C, generator=g) * 2.0 + 0.5)
+    gn_g = (1.0 + 0.2 * torch.randn(C, generator=g)).float()
+    gn_b = (0.3 * torch.randn(C, generator=g)).float()
+    xs = x.view(samples, rows, G, C // G)
+    mean = xs.mean(dim=(1, 3), keepdim=True)
+    var = xs.var(dim=(1, 3), unbiased=False, keepdim=True)
+    a_ref = h16((((xs - mean) / torch.sqrt(var + 1e-6)).reshape(M, C) * gn_g + gn_b))
+    tok_ref, out_ref = _chain_reference(a_ref, None, w, 3, rows)
+
+    x16 = x.half().to(DEV)
+    gd = hip.GroupNormDesc(samples, rows, C, G, C, C, 1e-6, 0)
+    wsb = hip.groupnorm_workspace_bytes(gd)
+    gws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    gg, gb = gn_g.to(DEV), gn_b.to(DEV)
+    # (1) separate launches
+    a16 = torch.empty_like(x16)
+    hip.groupnorm_silu(gd, x16.data_ptr(), gg.data_ptr(), gb.data_ptr(), a16.data_ptr(), gws.data_ptr(), gws.numel())
+    tok1, out1, ncol = _run_chain(a16, None, w, 3, M, rows)
+    # (2) statistics only + the apply in the chain's prologue
+    stat = torch.zeros(samples * G * 2, dtype=torch.float32, device=DEV)
+    hip.groupnorm_stats(gd, x16.data_ptr(), stat.data_ptr(), gws.data_ptr(), gws.numel())
+    tok2, out2, _ = _run_chain(x16, None, w, 3, M, rows, gn=(stat, gg, gb, G, rows))
+    close(tok2[:M, :C], tok_ref)
+    close(out2[:M, :ncol], out_ref)
+    bad = (tok1 != tok2).any(dim=1).nonzero().flatten().tolist()
+    assert not bad, f"prologue GroupNorm differs from the separate launch in token rows {bad[:8]} ... ({len(bad)} rows)"
+    assert torch.equal(out1, out2)
+    # rejected: with a stage-A residual, or with samples that are not whole 16-row fragments
+    d = hip.RowChainDesc(M, C, C, C, C, 3 * C, 3, rows, max(frames, 1), 1e-5, G, rows)
+    with pytest.raises(hip.RcdmError):
+        hip.rowchain(d, x16.data_ptr(), x16.data_ptr(), tok2.data_ptr(), gg.data_ptr(), gg.data_ptr(), gb.data_ptr(), 0,
+                     x16.data_ptr(), 0, 0, out2.data_ptr(), gn_stat=stat.data_ptr(), gn_g=gg.data_ptr(), gn_b=gb.data_ptr())
+    d.gn_rows = rows + 8
+    with pytest.raises(hip.RcdmError):
+        hip.rowchain(d, x16.data_ptr(), 0, tok2.data_ptr(), gg.data_ptr(), gg.data_ptr(), gb.data_ptr(), 0,
+                     x16.data_ptr(), 0, 0, out2.data_ptr(), gn_stat=stat.data_ptr(), gn_g=gg.data_ptr(), gn_b=gb.data_ptr())

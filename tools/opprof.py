@@ -45,6 +45,8 @@ def algorithmic_work(tag):
         return 4e-9 * rows * kv["F"] * C, 8e-6 * rows * C
     if kind == "groupnorm":
         return None, 6e-6 * kv["S"] * kv["R"] * kv["C"]
+    if kind == "groupnorm_stats":
+        return None, 2e-6 * kv["S"] * kv["R"] * kv["C"]
     if kind == "layernorm":
         return None, 4e-6 * kv["M"] * kv["C"]
     return None, None
