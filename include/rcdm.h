@@ -252,6 +252,10 @@ int rcdm_ff_fused(const rcdm_ff_desc* d, const void* x, const float* ln_gamma, c
  *     y[m][:]   = LayerNorm(tok[m][:]) * gamma + beta (+ pe[(m / rows_per_frame) % frames][:])
  *     tail 1 / 3:  out[m][0 : tail*C] = y[m][:] W_t^T          (no bias; W_t = fp32 [tail*C][C], e.g. [to_q; to_k; to_v])
  *     tail 0:      out[m][:] = tok[m][:] + FF_geglu(y[m][:])   (as rcdm_ff_fused; may be written in place of tok)
+ *     tail 2:      out[m][:] = z_res[m][:] + ((tok[m][:] + FF_geglu(y[m][:])) W_z^T + z_bias)   — the block's proj_out and the
+ *                  residual add of Transformer3DModel / TemporalTransformer3DModel.forward (attention.py:352-363,
+ *                  motion_module.py:170-176) ride too; the feed-forward's output rows are NOT stored (tok keeps the rows
+ *                  stage A wrote).  Needs res, no pe.  W_z = fp32 [C][C], passed to rcdm_pack_rowchain as wt.
  *   replaces, in BasicTransformerBlock.forward / Transformer3DModel.forward (attention.py:330,479-514) and
  *   TemporalTransformer3DModel / TemporalTransformerBlock.forward (motion_module.py:166,234-243,299-302):
  *     proj_in -> norm1 -> [to_q | to_k | to_v]                         (res = NULL, tail 3)
@@ -269,20 +273,21 @@ int rcdm_ff_fused(const rcdm_ff_desc* d, const void* x, const float* ln_gamma, c
 typedef struct {
   int32_t M, C;
   int32_t lda, ldr, ldt, ldo;      /* row strides in elements, multiples of 8 (ldr only with res) */
-  int32_t tail;                    /* 0 = feed-forward, 1 = GEMM to C columns, 3 = GEMM to 3C columns */
+  int32_t tail;                    /* 0 = feed-forward, 1 = GEMM to C columns, 2 = feed-forward + projection, 3 = GEMM to 3C */
   int32_t rows_per_frame, frames;  /* only with pe */
   float eps;                       /* LayerNorm eps (1e-5) */
   int32_t gn_groups, gn_rows;      /* only with gn_stat: groups and rows per sample of the GroupNorm */
+  int32_t ldz;                     /* row stride of z_res (tail 2) */
 } rcdm_rowchain_desc;
 int rcdm_rowchain_supported(int32_t C);
 size_t rcdm_rowchain_stream_bytes(int32_t C, int32_t tail);
-/* wa [C][C]; tail 1 / 3: wt [tail*C][C]; tail 0: w1 [8C][C], b1 [8C], w2 [C][4C] and b1_packed [8C] (out) */
+/* wa [C][C]; tail 1 / 3: wt [tail*C][C]; tail 0 / 2: w1 [8C][C], b1 [8C], w2 [C][4C] and b1_packed [8C] (out); tail 2: wt [C][C] */
 int rcdm_pack_rowchain(const float* wa, int32_t C, int32_t tail, const float* wt, const float* w1, const float* b1,
                        const float* w2, void* wstream, float* b1_packed, void* stream);
 int rcdm_rowchain(const rcdm_rowchain_desc* d, const void* a_in, const void* res, void* tok, const float* a_bias,
                   const float* ln_gamma, const float* ln_beta, const float* pe, const void* wstream, const float* b1_packed,
                   const float* b2, void* out, const float* gn_stat, const float* gn_gamma, const float* gn_beta,
-                  void* stream);
+                  const void* z_res, const float* z_bias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row softmax: y[m][n] = softmax over n of (scale * x[m][n]); f16 rows, fp32 math, N % 8 == 0, N <= 4096, scale > 0.

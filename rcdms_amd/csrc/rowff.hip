@@ -4,6 +4,7 @@
 //   rcdm_rowchain :  tok = a W_a^T + b_a (+ res);  y = LayerNorm(tok) (+ pe);  then one of
 //                      out = y W_t^T                      (N = C: cross-attention query, N = 3C: fused q | k | v)
 //                      out = tok + FeedForward_geglu(y)   (y computed with the feed-forward's own LayerNorm)
+//                      out = z_res + (tok + FeedForward_geglu(y)) W_z^T + b_z     (tail 2: the block's proj_out rides too)
 // Replace, per launch, the chains the library otherwise runs as 3-5 launches with every intermediate tensor in HBM:
 //   * nn.LayerNorm -> diffusers FeedForward(dim, activation_fn="geglu") -> + hidden_states
 //     (BasicTransformerBlock.forward src/models/attention.py:514, TemporalTransformerBlock.forward motion_module.py:243);
@@ -47,7 +48,7 @@
 
 namespace {
 
-enum { TAIL_FF = 0, TAIL_N1 = 1, TAIL_N3 = 3 };
+enum { TAIL_FF = 0, TAIL_N1 = 1, TAIL_FFP = 2, TAIL_N3 = 3 };   // FFP: feed-forward, then a C x C projection (+ bias + residual)
 
 struct RowArgs {
   const f16* a_in;     // [M][lda]: stage-A input rows (HAS_A), else the rows the LayerNorm reads (and the FF residual)
@@ -61,10 +62,12 @@ struct RowArgs {
   const float* pe;     // [frames][C] (LN_PE)
   const float* b1p;    // [8C] packed (TAIL_FF): per (group, pair) 16 hidden biases then their 16 gate biases
   const float* b2;     // [C] (TAIL_FF)
+  const f16* z_res;     // [M][ldz] residual of the trailing projection (TAIL_FFP)
+  const float* z_bias;  // [C] (TAIL_FFP)
   const float* gn_stat; // [samples][gn_G][2] = (mean, rstd) of the GroupNorm whose apply runs in the prologue (HAS_A && !A_RES), or null
   const float* gn_g;    // [C] GroupNorm weight
   const float* gn_b;    // [C] GroupNorm bias
-  int M, lda, ldr, ldt, ldo;
+  int M, lda, ldr, ldt, ldo, ldz;
   int rows_per_frame, frames;
   int gn_G, gn_rows;    // groups; rows per GroupNorm sample (>= the block's rows: a block meets at most two samples)
   float eps;
@@ -78,13 +81,14 @@ __global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
   constexpr int CHB = CHF * 1024;   // chunk bytes
   constexpr int NG = C / 8;         // feed-forward: groups of 32 hidden units (4C / 32)
   constexpr int NCH_A = HAS_A ? NK : 0;                                   // stage A: NK * NOF fragments
-  constexpr int NCH_T = TAIL == TAIL_FF ? 3 * NG : TAIL * NK;             // tail: FF 3 chunks per group; GEMM NK per C columns
+  constexpr bool IS_FF = TAIL == TAIL_FF || TAIL == TAIL_FFP;
+  constexpr int NCH_T = IS_FF ? 3 * NG + (TAIL == TAIL_FFP ? NK : 0) : TAIL * NK;   // FF 3 chunks per group; GEMM NK per C columns
   constexpr int NCH = NCH_A + NCH_T;
   constexpr int NT = NW * 64;
   constexpr int PPW = CHF / NW;     // DMA pieces per wave and chunk
   static_assert(CHF % NW == 0, "chunk fragments must divide over the waves");
   static_assert(NOF == CHF && CHF % PD == 0 && CHF >= 20 && NOF % 2 == 0, "chunk geometry");
-  constexpr int PAR0 = R * CHB;     // parameter region (floats): [a_bias C][gamma C][beta C][pe frames*C][b1p 8C]
+  constexpr int PAR0 = R * CHB;     // parameter region (floats): [a_bias C][gamma C][beta C][pe frames*C][b1p 8C][b2 C | z_bias C]
   constexpr int RS = 2 * C + 16;    // staged output row (bytes)
   static_assert(NW * 16 * RS <= R * CHB, "epilogue staging exceeds the ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,7 +100,8 @@ __global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
   const int row = row0 + l15;
   const bool live = row < p.M;
   const int oG = HAS_A ? C : 0, oB = oG + C, oPE = oB + C, oT = oPE + (LN_PE ? p.frames * C : 0);
-  const int oGN = oT + (TAIL == TAIL_FF ? 8 * C : 0);   // [2 samples][scale C | shift C] of the prologue GroupNorm
+  const int oZ = oT + (IS_FF ? 8 * C : 0);              // [b2 C][z_bias C] (TAIL_FFP)
+  const int oGN = oZ + (TAIL == TAIL_FFP ? 2 * C : 0);  // [2 samples][scale C | shift C] of the prologue GroupNorm
   const int npar = oGN;
 
   const __amdgpu_buffer_rsrc_t rsrcW =
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
         for (int j = 0; j < 8; ++j) tk[s][j] = (f16)0.f;
     }
   }
-  constexpr int NB4_MAX = ((HAS_A ? C : 0) + 2 * C + (LN_PE ? 8 * C : 0) + (TAIL == TAIL_FF ? 8 * C : 0)) / 4;  // <= 8 frames
+  constexpr int NB4_MAX = ((HAS_A ? C : 0) + 2 * C + (LN_PE ? 8 * C : 0) + (IS_FF ? 8 * C : 0) + (TAIL == TAIL_FFP ? 2 * C : 0)) / 4;  // <= 8 frames
   constexpr int NB4_PER = (NB4_MAX + NT - 1) / NT;
   f32x4 bq[NB4_PER];
 #pragma unroll
@@ -146,7 +151,9 @@ __global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
     else if (idx < oB) src = p.ln_g + (idx - oG);
     else if (idx < oPE) src = p.ln_b + (idx - oB);
     else if (LN_PE && idx < oT) src = p.pe + (idx - oPE);
-    else src = p.b1p + (idx - oT);
+    else if (idx < oZ) src = p.b1p + (idx - oT);
+    else if (idx < oZ + C) src = p.b2 + (idx - oZ);
+    else src = p.z_bias + (idx - oZ - C);
     bq[i] = *(const f32x4*)src;
   }
   // GroupNorm apply in the prologue (attention.py:328-330 / motion_module.py:162-166: norm, then proj_in): this block's
@@ -326,11 +333,14 @@ __global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
     }
   }
 
-  if constexpr (TAIL != TAIL_FF) {
-    // ---- tail GEMM  out[M][TAIL * C] = y W_t^T: groups of NOF / 2 output fragments (NK / 2 chunks each); a group's
-    // f16 results are stored 16 bytes per lane right after the next hand-over
-    constexpr int NGRP = 2 * TAIL;
-    f16x8 pend[NOF / 4];
+  // ---- a GEMM with N = NGRP * C / 2 whose B operands are xr, in groups of NOF / 2 output fragments (NK / 2 chunks each); a
+  // group's f16 results are stored 16 bytes per lane right after the next hand-over.  ZADD (the trailing projection of
+  // TAIL_FFP): + z_bias, rounded, + z_res, rounded — nn.Linear, then the block's residual add (attention.py:352-363,
+  // motion_module.py:170-176); the residual rows are requested at the group's first hand-over
+  auto gemm_groups = [&](auto ngrp_c, auto zadd_c) __attribute__((always_inline)) {
+    constexpr int NGRP = decltype(ngrp_c)::value;
+    constexpr bool ZADD = decltype(zadd_c)::value;
+    f16x8 pend[NOF / 4], zr[ZADD ? NOF / 4 : 1];
     int pend_col = 0;
     auto store_pend = [&]() __attribute__((always_inline)) {
       if (live) {
@@ -348,22 +358,44 @@ __global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
           acc[fi] = mm(w, xr[s], s == 0 ? z4 : acc[fi]);
         };
         if (cc == 0)
-          run_chunk(mf, nothing, [&]() __attribute__((always_inline)) { if (grp > 0) store_pend(); });
+          run_chunk(mf, nothing, [&]() __attribute__((always_inline)) {
+            if (grp > 0) store_pend();
+            if constexpr (ZADD) {
+              const f16* zp = p.z_res + (size_t)(live ? row : 0) * p.ldz + grp * (C / 2) + 8 * kg;
+#pragma unroll
+              for (int m = 0; m < NOF / 4; ++m) zr[m] = ld16(zp + 32 * m);
+            }
+          });
         else
           run_chunk(mf, nothing, no_stores);
       }
 #pragma unroll
-      for (int m = 0; m < NOF / 4; ++m)
+      for (int m = 0; m < NOF / 4; ++m) {
+        if constexpr (ZADD) {
+          const float* bz = par + oZ + C + grp * (C / 2) + 32 * m + 8 * kg;
+          const f32x4 b0 = *(const f32x4*)bz, b1 = *(const f32x4*)(bz + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pend[m][e] = (f16)acc[2 * m][e];
-          pend[m][4 + e] = (f16)acc[2 * m + 1][e];
+          for (int e = 0; e < 4; ++e) {
+            pend[m][e] = (f16)((float)(f16)(acc[2 * m][e] + b0[e]) + (float)zr[m][e]);
+            pend[m][4 + e] = (f16)((float)(f16)(acc[2 * m + 1][e] + b1[e]) + (float)zr[m][4 + e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pend[m][e] = (f16)acc[2 * m][e];
+            pend[m][4 + e] = (f16)acc[2 * m + 1][e];
+          }
         }
+      }
       pend_col = grp * (C / 2);
     }
     wait_lgkm0();
     wait_vm<0>();
     store_pend();
+  };
+
+  if constexpr (!IS_FF) {
+    gemm_groups(std::integral_constant<int, 2 * TAIL>{}, std::false_type{});
     return;
   } else {
     // ---- tail feed-forward.  Chunk order in the stream: A_0, then per group g: B_g, A_{g+1}, C_g  (A / B = GEMM1 of the
@@ -437,6 +469,36 @@ __global__ __launch_bounds__(NW * 64) void row_chain_kernel(const RowArgs p) {
     run_chunk(g1B, sliceA, no_stores);
 #pragma unroll
     for (int i = 0; i < CHF; ++i) sliceB(i);
+    if constexpr (TAIL == TAIL_FFP) {
+      // the feed-forward's residual rows (this wave's own stage-A stores: read back past the vector L1) are requested at
+      // the last chunk's hand-over; then x2 = f16(f16(acc) + b2 + tok) — the roundings of the staged epilogue below — is, in
+      // the P layout, the B operand of the trailing projection, which runs on as two more output groups of the stream
+      f16x8 tkr[NK];
+      run_chunk(g2, nothing, [&]() __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rsrcT = __builtin_amdgcn_make_buffer_rsrc((void*)p.tok, 0, 0x7FFFFFFF, 0x00020000);
+        const int off = ((live ? row : 0) * p.ldt + 8 * kg) * 2;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+          Pack16 t;
+          t.v = __builtin_amdgcn_raw_buffer_load_b128(rsrcT, off + 64 * s, 0, 16);
+          tkr[s] = t.h;
+        }
+      });
+#pragma unroll
+      for (int s = 0; s < NK; ++s) {
+        const float* b2p = par + oZ + 32 * s + 8 * kg;
+        const f32x4 b0 = *(const f32x4*)b2p, b1 = *(const f32x4*)(b2p + 4);
+        f16x8 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y[e] = (f16)((float)(f16)oacc[2 * s][e] + b0[e] + (float)tkr[s][e]);
+          y[4 + e] = (f16)((float)(f16)oacc[2 * s + 1][e] + b1[e] + (float)tkr[s][4 + e]);
+        }
+        xr[s] = y;
+      }
+      gemm_groups(std::integral_constant<int, 2>{}, std::true_type{});
+      return;
+    }
     run_chunk(g2, nothing, no_stores);  // C of the last group
     wait_lgkm0();
     wait_vm<0>();    // the zero-fill pieces issued past the end of the stream (and stage A's stores)
@@ -521,8 +583,9 @@ __global__ void pack_pgemm_kernel(const float* __restrict__ w, int C, int n_bloc
 
 // feed-forward: fp32 [8C][C] / [8C] / [C][4C] -> chunks A_0, then per group g: B_g, A_{g+1} (absent for the last group),
 // C_g; the k-slots of the GEMM2 fragments follow the D layout of the GEGLU values
+// pperm: the rows of GEMM2 in the P layout (its accumulators become the operand of a trailing projection, TAIL_FFP)
 __global__ void pack_ff_stream_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-                                      int C, f16* __restrict__ ws, float* __restrict__ b1p) {
+                                      int C, f16* __restrict__ ws, float* __restrict__ b1p, int pperm) {
   const int NK = C / 32, CHF = 2 * NK;
   const size_t total = (size_t)12 * C * C;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -548,7 +611,8 @@ __global__ void pack_ff_stream_kernel(const float* __restrict__ w1, const float*
       v = w1[(size_t)(gate ? 4 * C + hr : hr) * C + 32 * s + 8 * kg + j];
     } else {
       const int hid = 32 * g + (j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4));
-      v = w2[(size_t)(16 * f + l15) * (4 * C) + hid];
+      const int n = pperm ? 32 * (f >> 1) + 8 * (l15 >> 2) + 4 * (f & 1) + (l15 & 3) : 16 * f + l15;
+      v = w2[(size_t)n * (4 * C) + hid];
     }
     ws[idx] = (f16)v;
     if (idx < (size_t)8 * C) {  // packed bias: [(g, pair)][16 hidden | 16 gate]
@@ -563,7 +627,8 @@ template <bool HAS_A, bool A_RES, bool LN_PE, int TAIL>
 int launch_chain(const RowArgs& a, hipStream_t stream) {
   constexpr int C = 320, NW = 10, R = 7, PD = 2;
   constexpr int CHB = 2 * (C / 32) * 1024;
-  const int npar = (HAS_A ? C : 0) + 2 * C + (LN_PE ? a.frames * C : 0) + (TAIL == TAIL_FF ? 8 * C : 0);
+  const int npar = (HAS_A ? C : 0) + 2 * C + (LN_PE ? a.frames * C : 0) + (TAIL == TAIL_FF || TAIL == TAIL_FFP ? 8 * C : 0) +
+                   (TAIL == TAIL_FFP ? 2 * C : 0);
   const int lds = R * CHB + (npar + (a.gn_stat ? 4 * C : 0)) * 4;
   if (lds > 160 * 1024) return RCDM_ESHAPE;
   static bool attr_set[64] = {};
@@ -591,8 +656,8 @@ int rcdm_rowchain_supported(int32_t C) { return C == 320 ? 1 : 0; }
 size_t rcdm_ff_stream_bytes(int32_t C) { return C > 0 ? (size_t)24 * C * C : 0; }
 
 size_t rcdm_rowchain_stream_bytes(int32_t C, int32_t tail) {
-  if (C <= 0 || !(tail == 0 || tail == 1 || tail == 3)) return 0;
-  return (size_t)2 * C * C * (1 + (tail == 0 ? 12 : tail));
+  if (C <= 0 || tail < 0 || tail > 3) return 0;
+  return (size_t)2 * C * C * (1 + (tail == 0 ? 12 : tail == 2 ? 13 : tail));
 }
 
 int rcdm_pack_ff_stream(const float* w1, const float* b1, const float* w2, int32_t C, void* wstream, float* b1_packed,
@@ -600,23 +665,27 @@ int rcdm_pack_ff_stream(const float* w1, const float* b1, const float* w2, int32
   if (!w1 || !b1 || !w2 || !wstream || !b1_packed || C <= 0) return RCDM_EINVAL;
   if (C % 32) return RCDM_ESHAPE;
   hipLaunchKernelGGL(pack_ff_stream_kernel, dim3(grid_for((size_t)12 * C * C)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, C,
-                     (f16*)wstream, b1_packed);
+                     (f16*)wstream, b1_packed, 0);
   return rcdm_check_launch();
 }
 
 int rcdm_pack_rowchain(const float* wa, int32_t C, int32_t tail, const float* wt, const float* w1, const float* b1,
                        const float* w2, void* wstream, float* b1_packed, void* stream) {
   if (!wa || !wstream || C <= 0) return RCDM_EINVAL;
-  if (C % 32 || !(tail == 0 || tail == 1 || tail == 3)) return RCDM_ESHAPE;
-  if (tail == 0 ? (!w1 || !b1 || !w2 || !b1_packed) : !wt) return RCDM_EINVAL;
+  if (C % 32 || tail < 0 || tail > 3) return RCDM_ESHAPE;
+  const bool ff = tail == 0 || tail == 2;
+  if ((ff && (!w1 || !b1 || !w2 || !b1_packed)) || (tail != 0 && !wt)) return RCDM_EINVAL;
   f16* ws = (f16*)wstream;
   hipLaunchKernelGGL(pack_pgemm_kernel, dim3(grid_for((size_t)C * C)), dim3(256), 0, (hipStream_t)stream, wa, C, 1, ws);
   ws += (size_t)C * C;
-  if (tail == 0)
+  if (ff) {
     hipLaunchKernelGGL(pack_ff_stream_kernel, dim3(grid_for((size_t)12 * C * C)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, C,
-                       ws, b1_packed);
-  else
-    hipLaunchKernelGGL(pack_pgemm_kernel, dim3(grid_for((size_t)tail * C * C)), dim3(256), 0, (hipStream_t)stream, wt, C, tail, ws);
+                       ws, b1_packed, tail == 2 ? 1 : 0);
+    ws += (size_t)12 * C * C;
+  }
+  if (tail != 0)   // tail 2: wt = the trailing [C][C] projection
+    hipLaunchKernelGGL(pack_pgemm_kernel, dim3(grid_for((size_t)(ff ? 1 : tail) * C * C)), dim3(256), 0, (hipStream_t)stream, wt, C,
+                       ff ? 1 : tail, ws);
   return rcdm_check_launch();
 }
 
@@ -634,14 +703,18 @@ int rcdm_ff_fused(const rcdm_ff_desc* d, const void* x, const float* ln_gamma, c
 
 int rcdm_rowchain(const rcdm_rowchain_desc* d, const void* a_in, const void* res, void* tok, const float* a_bias,
                   const float* ln_gamma, const float* ln_beta, const float* pe, const void* wstream, const float* b1_packed,
-                  const float* b2, void* out, const float* gn_stat, const float* gn_gamma, const float* gn_beta, void* stream) {
+                  const float* b2, void* out, const float* gn_stat, const float* gn_gamma, const float* gn_beta,
+                  const void* z_res, const float* z_bias, void* stream) {
   if (!d || !a_in || !tok || !a_bias || !ln_gamma || !ln_beta || !wstream || !out) return RCDM_EINVAL;
-  const int ncol = d->tail == 0 ? d->C : d->tail * d->C;
+  const int ncol = d->tail == 0 || d->tail == 2 ? d->C : d->tail * d->C;
   if (d->M <= 0 || d->lda < d->C || d->ldt < d->C || d->ldo < ncol || ((d->lda | d->ldt | d->ldo) & 7)) return RCDM_EINVAL;
   if (res && (d->ldr < d->C || (d->ldr & 7))) return RCDM_EINVAL;
   if (pe && (d->rows_per_frame <= 0 || d->frames <= 0 || d->frames > 8)) return RCDM_EINVAL;
-  if (d->tail == 0 && (!b1_packed || !b2)) return RCDM_EINVAL;
-  if (d->C != 320 || !(d->tail == 0 || d->tail == 1 || d->tail == 3)) return RCDM_ESHAPE;
+  if ((d->tail == 0 || d->tail == 2) && (!b1_packed || !b2)) return RCDM_EINVAL;
+  if (d->C != 320 || d->tail < 0 || d->tail > 3) return RCDM_ESHAPE;
+  if (d->tail == 2) {   // feed-forward + trailing projection: the form the engine uses (stage-A residual, no pe)
+    if (!res || pe || !z_res || !z_bias || d->ldz < d->C || (d->ldz & 7)) return RCDM_EINVAL;
+  }
   if (gn_stat) {   // GroupNorm apply on the incoming rows: only the form without a stage-A residual has the operand free
     if (res || !gn_gamma || !gn_beta || d->gn_groups <= 0 || d->gn_rows <= 0) return RCDM_EINVAL;
     if (d->C % d->gn_groups || d->gn_rows % 16 || d->gn_rows < 160) return RCDM_ESHAPE;
@@ -651,6 +724,7 @@ int rcdm_rowchain(const rcdm_rowchain_desc* d, const void* a_in, const void* res
   a.a_bias = a_bias; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.pe = pe; a.b1p = b1_packed; a.b2 = b2;
   a.M = d->M; a.lda = d->lda; a.ldr = d->ldr; a.ldt = d->ldt; a.ldo = d->ldo;
   a.rows_per_frame = pe ? d->rows_per_frame : 1; a.frames = pe ? d->frames : 1; a.eps = d->eps;
+  a.z_res = (const f16*)z_res; a.z_bias = z_bias; a.ldz = d->ldz;
   a.gn_stat = gn_stat; a.gn_g = gn_gamma; a.gn_b = gn_beta; a.gn_G = d->gn_groups; a.gn_rows = d->gn_rows;
   hipStream_t s = (hipStream_t)stream;
 #define RCDM_CHAIN(T)                                                                  \
@@ -659,6 +733,7 @@ int rcdm_rowchain(const rcdm_rowchain_desc* d, const void* a_in, const void* res
   switch (d->tail) {
     case 0: return RCDM_CHAIN(TAIL_FF);
     case 1: return RCDM_CHAIN(TAIL_N1);
+    case 2: return launch_chain<true, true, false, TAIL_FFP>(a, s);
     default: return RCDM_CHAIN(TAIL_N3);
   }
 #undef RCDM_CHAIN

@@ -338,17 +338,29 @@ class Packer:
 
     def chain(self, wa_key, tail, wt_keys=(), ff_keys=None):
         """(weight stream, packed b1 | None) for rcdm_rowchain: stage-A matrix wa_key [C][C] (a Linear or 1x1 conv weight),
-        then tail 1 / 3: the stacked [tail*C][C] matrices wt_keys, tail 0: the feed-forward (w1, b1, w2) keys.  None when
-        the library has no chain kernel for this width or a tail projection carries a bias."""
+        then tail 1 / 3: the stacked [tail*C][C] matrices wt_keys, tail 0: the feed-forward (w1, b1, w2) keys, tail 2: the
+        feed-forward keys and wt_keys = (the trailing [C][C] projection,) whose bias the launch takes separately.  None
+        when the library has no chain kernel for this width or a tail 1 / 3 projection carries a bias."""
         if not ROW_CHAIN or any(not self.has(k) for k in (wa_key, *wt_keys, *(ff_keys or ()))):
             return None
         Cc = self.sd[wa_key].shape[0]
         if not hip.rowchain_supported(Cc) or self.sd[wa_key].numel() != Cc * Cc:
             return None
-        if any(self.has(k.replace(".weight", ".bias")) for k in wt_keys):
+        if tail != 2 and any(self.has(k.replace(".weight", ".bias")) for k in wt_keys):
             return None
         wa = self.f32(wa_key).reshape(Cc, Cc).contiguous()
         ws = torch.empty(hip.rowchain_stream_bytes(Cc, tail), dtype=torch.uint8, device=self.device)
+        if tail == 2:
+            w1, b1, w2 = (self.f32(k) for k in ff_keys)
+            wz = self.f32(wt_keys[0])
+            if w1.shape != (8 * Cc, Cc) or w2.shape != (Cc, 4 * Cc) or wz.numel() != Cc * Cc:
+                return None
+            wz = wz.reshape(Cc, Cc).contiguous()
+            b1p = torch.empty(8 * Cc, dtype=torch.float32, device=self.device)
+            hip.pack_rowchain(wa.data_ptr(), Cc, 2, wz.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), ws.data_ptr(),
+                              b1p.data_ptr())
+            self._tmp += [wa, wz, w1, b1, w2]
+            return ws, b1p
         if tail:
             wt = torch.cat([self.f32(k) for k in wt_keys], dim=0).contiguous()
             if tuple(wt.shape) != (tail * Cc, Cc):
@@ -438,6 +450,12 @@ def pack_transformer(pk, p):
     w.gn_g, w.gn_b = pk.vec(p + "norm.weight"), pk.vec(p + "norm.bias")
     w.proj_in, w.proj_in_b = pk.mat_f16(p + "proj_in.weight"), pk.vec(p + "proj_in.bias")
     w.proj_out, w.proj_out_b = pk.mat_f16(p + "proj_out.weight"), pk.vec(p + "proj_out.bias")
+    # ... and the block's last chain with proj_out + the transformer's residual behind the feed-forward
+    w.ch_o2_ffz = None
+    if CHAIN_PROJ and w.ch_o2_ff is not None:
+        t = p + "transformer_blocks.0."
+        w.ch_o2_ffz = pk.chain(t + "attn2.to_out.0.weight", 2, wt_keys=(p + "proj_out.weight",),
+                               ff_keys=(t + "ff.net.0.proj.weight", t + "ff.net.0.proj.bias", t + "ff.net.2.weight"))
     return w
 
 
@@ -465,7 +483,7 @@ def pack_motion(pk, p, n_attn):
     w.ff_stream = pk.ff_stream(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight")
     # row-stationary chains: proj_in -> norms[0] + pe -> qkv;  to_out + res -> norms[1] + pe -> qkv;  to_out + res ->
     # ff_norm -> ff -> + res
-    w.chains = None
+    w.chains = w.chain_ffz = None
     if n_attn == 2:
         a0, a1 = b + "attention_blocks.0.", b + "attention_blocks.1."
         qkv = lambda a: (a + "to_q.weight", a + "to_k.weight", a + "to_v.weight")
@@ -474,6 +492,9 @@ def pack_motion(pk, p, n_attn):
                        ff_keys=(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight"))]
         if all(c is not None for c in ch) and all(at.pe is not None for at in w.attn):
             w.chains = ch
+            if CHAIN_PROJ:   # proj_out + the module's residual behind the feed-forward (zero-initialised proj_out included)
+                w.chain_ffz = pk.chain(a1 + "to_out.0.weight", 2, wt_keys=(p + "proj_out.weight",),
+                                       ff_keys=(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight"))
     return w
 
 
@@ -515,25 +536,29 @@ FF_FUSE = os.environ.get("RCDM_FF_FUSE", "1") != "0"
 # rcdm_rowchain (rowff.hip): [C x C projection (+ residual) -> LayerNorm (+ pe) -> q | qkv projection or feed-forward] as one
 # row-stationary launch.  RCDM_ROWCHAIN=0 keeps the separate launches (same-process A/B).
 ROW_CHAIN = os.environ.get("RCDM_ROWCHAIN", "1") != "0"
+CHAIN_PROJ = os.environ.get("RCDM_CHAIN_PROJ", "1") != "0"   # proj_out + residual as the trailing stage of the feed-forward chain
 CHAIN_GN = os.environ.get("RCDM_CHAIN_GN", "1") != "0"   # GroupNorm apply in the prologue of the proj_in chain
 
 
-def emit_rowchain(plan, a_in, res, tok, a_bias, ln, pe, stream, tail, out, rows_per_frame=1, frames=1, b2=None, gn=None):
+def emit_rowchain(plan, a_in, res, tok, a_bias, ln, pe, stream, tail, out, rows_per_frame=1, frames=1, b2=None, gn=None,
+                  z=None):
     """tok = a_in W_a^T + a_bias (+ res);  y = LayerNorm(tok) (+ pe);  tail 1 / 3: out = y W_t^T;  tail 0: out = tok + FF(y).
     ln = (gamma, beta); stream = Packer.chain(...); gn = emit_groupnorm_stats(...): a_in is the RAW input of that
-    GroupNorm and the kernel applies it while loading its rows (res must be None)."""
+    GroupNorm and the kernel applies it while loading its rows (res must be None).  tail 2, z = (z_res rows, z_bias):
+    out = z_res + (tok + FF(y)) W_z^T + z_bias, the feed-forward's own output rows are not stored."""
     ws, b1p = stream
     M, C = a_in.M, a_in.C
     d = hip.RowChainDesc(M, C, a_in.ld, res.ld if res is not None else 0, tok.ld, out.ld, tail, rows_per_frame, frames, 1e-5,
-                         gn[3] if gn else 0, gn[4] if gn else 0)
+                         gn[3] if gn else 0, gn[4] if gn else 0, z[0].ld if z else 0)
 
     def op():
         hip.rowchain(d, a_in.ptr, res.ptr if res is not None else 0, tok.ptr, a_bias.data_ptr(), ln[0].data_ptr(),
                      ln[1].data_ptr(), pe.data_ptr() if pe is not None else 0, ws.data_ptr(),
                      b1p.data_ptr() if b1p is not None else 0, b2.data_ptr() if b2 is not None else 0, out.ptr,
-                     gn_stat=gn[0].ptr if gn else 0, gn_g=gn[1].data_ptr() if gn else 0, gn_b=gn[2].data_ptr() if gn else 0)
+                     gn_stat=gn[0].ptr if gn else 0, gn_g=gn[1].data_ptr() if gn else 0, gn_b=gn[2].data_ptr() if gn else 0,
+                     z_res=z[0].ptr if z else 0, z_bias=z[1].data_ptr() if z else 0)
     plan.add(op, f"rowchain M={M} C={C} tail={tail} res={int(res is not None)} pe={int(pe is not None)} gn={int(gn is not None)}")
-    plan.keep += [a_bias, ln[0], ln[1], pe, ws, b1p, b2]
+    plan.keep += [a_bias, ln[0], ln[1], pe, ws, b1p, b2, z[1] if z else None]
     plan.n_launch += 1
     plan.last_gemm = None
 
@@ -558,7 +583,7 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None)
     emit_gemm(plan, gg, ff2, C, 4 * C, tok, bias=ff2_b, residual=tok)
 
 
-def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False, ctx_img=None, pre=None):
+def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False, ctx_img=None, pre=None, post=None):
     """BasicTransformerBlock.forward (src/models/attention.py:479-526) in place on tok [n_seq*Lq][C]:
     h += attn1(LN1(h)); h += attn2(LN2(h), ctx); h += FF(LN3(h)).  ctx_kv: Rows [n_seq*L][2C] = [K | V] of the context.
     shared_half: the two halves of tok (the CFG halves of a denoising step) hold IDENTICAL rows on entry — everything up
@@ -594,6 +619,9 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
             emit_xattn(plan, qc, ctx_img, n_seq, heads, Lq, L, d_head, ao)
         else:
             emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), n_seq, heads, Lq, L, d_head, ao)
+        if post is not None:         # ... and the transformer's proj_out + residual behind it: post = (stream, x, bias, out)
+            emit_rowchain(plan, ao, tok, tok, w.o2_b, w.ln[2], None, post[0], 2, post[3], b2=w.ff2_b, z=(post[1], post[2]))
+            return
         if w.ch_o2_ff is not None:   # attn2.to_out + residual -> norm3 -> ff -> + residual in one launch
             emit_rowchain(plan, ao, tok, tok, w.o2_b, w.ln[2], None, w.ch_o2_ff, 0, tok, b2=w.ff2_b)
             return
@@ -625,8 +653,11 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     else:
         emit_groupnorm(plan, x.rows(0, M_s), n_s, g.hw, w.gn_g, w.gn_b, 1e-6, False, a.rows(0, M_s), groups)
         emit_gemm(plan, a.rows(0, M_s), w.proj_in, C, C, tok.rows(0, M_s), bias=w.proj_in_b)
-    emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img, pre=pre)
-    emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
+    post = (w.ch_o2_ffz, x, w.proj_out_b, out) if getattr(w, "ch_o2_ffz", None) is not None and w.has_cross else None
+    emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img, pre=pre,
+                     post=post)
+    if post is None:
+        emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
 
 
 def emit_ctx_kv(plan, w, ctx16, ctx_kv, n_seq=0, L=0, heads=0):
@@ -663,6 +694,9 @@ def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
         emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)
         emit_rowchain(plan, ao, tok, tok, a0.o_b, (a1.ln_g, a1.ln_b), a1.pe, w.chains[1], 3, qkv, g.hw, g.f)
         emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)
+        if w.chain_ffz is not None:
+            emit_rowchain(plan, ao, tok, tok, a1.o_b, w.ff_ln, None, w.chain_ffz, 2, out, b2=w.ff2_b, z=(x, w.proj_out_b))
+            return
         emit_rowchain(plan, ao, tok, tok, a1.o_b, w.ff_ln, None, w.chains[2], 0, tok, b2=w.ff2_b)
         emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
         return

@@ -58,7 +58,7 @@ class FFDesc(C.Structure):
 class RowChainDesc(C.Structure):
     _fields_ = [("M", C.c_int32), ("C", C.c_int32), ("lda", C.c_int32), ("ldr", C.c_int32), ("ldt", C.c_int32),
                 ("ldo", C.c_int32), ("tail", C.c_int32), ("rows_per_frame", C.c_int32), ("frames", C.c_int32),
-                ("eps", C.c_float), ("gn_groups", C.c_int32), ("gn_rows", C.c_int32)]
+                ("eps", C.c_float), ("gn_groups", C.c_int32), ("gn_rows", C.c_int32), ("ldz", C.c_int32)]
 
 
 class AttnDesc(C.Structure):
@@ -103,7 +103,7 @@ SYMBOLS = {
     "rcdm_rowchain_supported": (C.c_int, [_I]),
     "rcdm_rowchain_stream_bytes": (_SZ, [_I, _I]),
     "rcdm_pack_rowchain": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "rcdm_rowchain": (C.c_int, [C.POINTER(RowChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rcdm_rowchain": (C.c_int, [C.POINTER(RowChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rcdm_timestep_embed": (C.c_int, [_P, _I, _I, _P, _P]),
     "rcdm_small_linear": (C.c_int, [_P, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "rcdm_assemble_input": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -274,9 +274,9 @@ def pack_rowchain(wa, Cc, tail, wt, w1, b1, w2, wstream, b1p, stream=None):
 
 
 def rowchain(desc, a_in, res, tok, a_bias, ln_g, ln_b, pe, wstream, b1p, b2, out, stream=None, gn_stat=None, gn_g=None,
-             gn_b=None):
+             gn_b=None, z_res=None, z_bias=None):
     _check(load().rcdm_rowchain(C.byref(desc), a_in, res, tok, a_bias, ln_g, ln_b, pe, wstream, b1p, b2, out,
-                                gn_stat, gn_g, gn_b, stream_ptr() if stream is None else stream), "rcdm_rowchain")
+                                gn_stat, gn_g, gn_b, z_res, z_bias, stream_ptr() if stream is None else stream), "rcdm_rowchain")
 
 
 def pack_ff_stream(w1, b1, w2, Cc, wstream, b1p, stream=None):

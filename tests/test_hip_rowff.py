@@ -253,3 +253,51 @@ def test_rowchain_groupnorm_prologue(hiplib, frames, rows, samples):
     with pytest.raises(hip.RcdmError):
         hip.rowchain(d, x16.data_ptr(), 0, tok2.data_ptr(), gg.data_ptr(), gg.data_ptr(), gb.data_ptr(), 0,
                      x16.data_ptr(), 0, 0, out2.data_ptr(), gn_stat=stat.data_ptr(), gn_g=gg.data_ptr(), gn_b=gb.data_ptr())
+
+
+@pytest.mark.parametrize("M", [352, 2560])
+def test_rowchain_ff_then_projection(hiplib, M):
+    """tail 2: attn.to_out + res -> norm -> ff -> + res -> proj_out + bias -> + the block's input, one launch
+    (attention.py:505-514,352-363).  Against the reference arithmetic and against tail 0 followed by rcdm_gemm."""
+    from rcdms_amd import hip
+    C = 320
+    w, g = _chain_weights(C, 0, 0, 4242 + M)
+    wz = h16(torch.randn(C, C, generator=g) * C ** -0.5)
+    bz = 0.1 * torch.randn(C, generator=g)
+    a = h16(torch.randn(M, C, generator=g))
+    res = h16(torch.randn(M, C, generator=g) * 1.5)
+    zres = h16(torch.randn(M, C, generator=g))
+    tok_ref, ff_ref = _chain_reference(a, res, w, 0, 1)
+    out_ref = h16(F.linear(h16(ff_ref), wz, bz)) + zres
+
+    dev = {k: (v.to(DEV).contiguous() if v is not None else None) for k, v in w.items()}
+    wzd, bzd = wz.to(DEV).contiguous(), bz.to(DEV)
+    ws = torch.empty(hip.rowchain_stream_bytes(C, 2), dtype=torch.uint8, device=DEV)
+    assert ws.numel() == 2 * C * C * 14
+    b1p = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+    hip.pack_rowchain(dev["wa"].data_ptr(), C, 2, wzd.data_ptr(), dev["w1"].data_ptr(), dev["b1"].data_ptr(),
+                      dev["w2"].data_ptr(), ws.data_ptr(), b1p.data_ptr())
+    a16, z16 = a.half().to(DEV), zres.half().to(DEV)
+    tok = res.half().to(DEV)                         # in place on the residual stream, as the engine runs it
+    out = torch.full((M + 4, C + 8), 5.0, dtype=torch.float16, device=DEV)
+    d = hip.RowChainDesc(M, C, C, C, C, out.stride(0), 2, 1, 1, 1e-5, 0, 0, C)
+    args = (a16.data_ptr(), tok.data_ptr(), tok.data_ptr(), dev["ba"].data_ptr(), dev["ln_g"].data_ptr(), dev["ln_b"].data_ptr(), 0,
+            ws.data_ptr(), b1p.data_ptr(), dev["b2"].data_ptr(), out.data_ptr())
+    hip.rowchain(d, *args, z_res=z16.data_ptr(), z_bias=bzd.data_ptr())
+    torch.cuda.synchronize()
+    close(tok, tok_ref)                              # tok keeps stage A's rows (the feed-forward output is not stored)
+    close(out[:M, :C], out_ref)
+    assert (out[M:] == 5.0).all() and (out[:, C:] == 5.0).all(), "stores outside the result"
+    # the two-launch form: tail 0 in place, then proj_out as rcdm_gemm with bias + residual
+    _, ff2, _ = _run_chain(a16, res.half().to(DEV), w, 0, M, 1)
+    out2 = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    gd = hip.GemmDesc(M, C, C, ff2.stride(0), C, C, 1 | 4, 1, 0, 1.0, 0, 0)
+    wsz = torch.zeros(max(hip.gemm_workspace_bytes(gd), 16), dtype=torch.uint8, device=DEV)
+    hip.gemm(gd, ff2.data_ptr(), wzd.half().data_ptr(), bzd.data_ptr(), 0, z16.data_ptr(), out2.data_ptr(), wsz.data_ptr(), wsz.numel())
+    torch.cuda.synchronize()
+    close(out[:M, :C], out2.float().cpu())
+    # rejected without the residual / bias of the projection, or without a stage-A residual
+    with pytest.raises(hip.RcdmError):
+        hip.rowchain(d, *args)
+    with pytest.raises(hip.RcdmError):
+        hip.rowchain(d, a16.data_ptr(), 0, *args[2:], z_res=z16.data_ptr(), z_bias=bzd.data_ptr())

@@ -37,8 +37,10 @@ def algorithmic_work(tag):
     if kind == "ff_fused":
         return 2e-9 * kv["M"] * 12 * kv["C"] ** 2, 4e-6 * kv["M"] * kv["C"]
     if kind == "rowchain":
-        t = kv["tail"]
-        return 2e-9 * kv["M"] * kv["C"] ** 2 * (1 + (t if t else 12)), 2e-6 * kv["M"] * kv["C"] * (2 + kv["res"] + (t if t else 2))
+        t = kv["tail"]   # 0: feed-forward (12 C^2 per row), 2: feed-forward + projection (13), 1 / 3: GEMM to t*C columns
+        nmat = {0: 12, 2: 13}.get(t, t)
+        # rows moved: a_in, (res), tok written, then q / qkv out | tok re-read + out | tok re-read + z_res + out
+        return 2e-9 * kv["M"] * kv["C"] ** 2 * (1 + nmat), 2e-6 * kv["M"] * kv["C"] * (2 + kv["res"] + {0: 2, 2: 3}.get(t, t))
     if kind == "temporal_attn":
         C = kv["H"] * kv["d"]
         rows = kv["S"] * kv["F"] * kv["P"]
