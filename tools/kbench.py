@@ -300,6 +300,47 @@ def bench_chain(rounds, only=""):
                                                 0 if tail else b2.data_ptr(), out.data_ptr()), rounds)
         print(f"chain {name:27s} {fl / 1e9:8.1f} GF | launches {med:7.1f}us {fl / med / 1e6:6.0f}TF | rcdm_rowchain {med2:7.1f}us "
               f"(min {mn2:.1f}) {fl / med2 / 1e6:6.0f}TF", flush=True)
+        if tail == 0 and (not only or "proj_out" in only or only in name):
+            # ... -> proj_out + bias + the block's input: one more C x C GEMM launch, or tail 2 of the chain
+            wz, bz = torch.randn(C, C, device=DEV) * C ** -0.5, torch.randn(C, device=DEV)
+            wzh, xin, fin = wz.half().contiguous(), torch.randn(M, C, device=DEV).half(), torch.empty(M, C, device=DEV, dtype=torch.float16)
+
+            def chain_z():
+                chain()
+                hip.gemm(d0, out.data_ptr(), wzh.data_ptr(), bz.data_ptr(), 0, xin.data_ptr(), fin.data_ptr(), ws.data_ptr(), ws.numel())
+            flz = fl + 2.0 * M * C * C
+            medz, _ = timeit(chain_z, rounds)
+            wsz = torch.empty(hip.rowchain_stream_bytes(C, 2), dtype=torch.uint8, device=DEV)
+            hip.pack_rowchain(wa.data_ptr(), C, 2, wz.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), wsz.data_ptr(), b1p.data_ptr())
+            rz = hip.RowChainDesc(M, C, C, C, C, C, 2, 1, 1, 1e-5, 0, 0, C)
+            medz2, mnz2 = timeit(lambda: hip.rowchain(rz, a.data_ptr(), tok.data_ptr(), tok.data_ptr(), ba.data_ptr(), g.data_ptr(),
+                                                      b.data_ptr(), 0, wsz.data_ptr(), b1p.data_ptr(), b2.data_ptr(), fin.data_ptr(),
+                                                      z_res=xin.data_ptr(), z_bias=bz.data_ptr()), rounds)
+            print(f"chain {'L0 o+res -> LN -> FF -> proj_out':27s} {flz / 1e9:8.1f} GF | launches {medz:7.1f}us {flz / medz / 1e6:6.0f}TF | "
+                  f"rcdm_rowchain {medz2:7.1f}us (min {mnz2:.1f}) {flz / medz2 / 1e6:6.0f}TF", flush=True)
+        if tail == 3 and (not only or "GN" in only or only in name):
+            # GroupNorm (per frame) -> proj_in -> LN + pe -> qkv: four + three launches, or statistics + the chain with the apply inside
+            gd = hip.GroupNormDesc(M // 4096, 4096, C, 32, C, C, 1e-6, 0)
+            gws = torch.zeros(hip.groupnorm_workspace_bytes(gd), dtype=torch.uint8, device=DEV)
+            stat = torch.zeros(M // 4096 * 64, dtype=torch.float32, device=DEV)
+            xn = torch.empty(M, C, device=DEV, dtype=torch.float16)
+            d00 = hip.GemmDesc(M, C, C, C, C, 0, 1, 1, 0, 1.0, 0)
+
+            def chain_gn():
+                hip.groupnorm_silu(gd, a.data_ptr(), g.data_ptr(), b.data_ptr(), xn.data_ptr(), gws.data_ptr(), gws.numel())
+                hip.gemm(d00, xn.data_ptr(), wah.data_ptr(), ba.data_ptr(), 0, 0, tok.data_ptr(), ws.data_ptr(), ws.numel())
+                hip.layernorm(lnd, tok.data_ptr(), g.data_ptr(), b.data_ptr(), pe.data_ptr(), y.data_ptr())
+                hip.gemm(dt, y.data_ptr(), wth.data_ptr(), 0, 0, 0, out.data_ptr(), ws.data_ptr(), ws.numel())
+            medg, _ = timeit(chain_gn, rounds)
+            rg = hip.RowChainDesc(M, C, C, 0, C, ncol, 3, 4096, 5, 1e-5, 32, 4096)
+
+            def fused_gn():
+                hip.groupnorm_stats(gd, a.data_ptr(), stat.data_ptr(), gws.data_ptr(), gws.numel())
+                hip.rowchain(rg, a.data_ptr(), 0, tok.data_ptr(), ba.data_ptr(), g.data_ptr(), b.data_ptr(), pe.data_ptr(), wsr.data_ptr(),
+                             0, 0, out.data_ptr(), gn_stat=stat.data_ptr(), gn_g=g.data_ptr(), gn_b=b.data_ptr())
+            medg2, mng2 = timeit(fused_gn, rounds)
+            print(f"chain {'L0 GN -> proj_in -> LN -> qkv':27s} {fl / 1e9:8.1f} GF | launches {medg:7.1f}us {fl / medg / 1e6:6.0f}TF | "
+                  f"stats + rcdm_rowchain {medg2:7.1f}us (min {mng2:.1f}) {fl / medg2 / 1e6:6.0f}TF", flush=True)
 
 
 if __name__ == "__main__":
