@@ -96,6 +96,8 @@ class Plan:
         return sum(b.nbytes for b in self.bufs.values())
 
     def add(self, fn, tag="misc"):
+        if _DROP and tag.split()[0] in _DROP:   # timing experiments only (RCDM_DROP_OPS): the plan computes garbage
+            return
         self.ops.append(fn)
         self.tags.append(tag)
 
@@ -103,6 +105,10 @@ class Plan:
         for op in (self.ops if ops is None else ops):
             op()
 
+
+# upper bound of a fusion before it is built: RCDM_DROP_OPS=layernorm,temporal_attn,... leaves every op of those kinds out of
+# the launch plan (wrong results; tools/ab_env.sh RCDM_DROP_OPS "" layernorm gives what removing all of them could buy at most)
+_DROP = frozenset(k for k in os.environ.get("RCDM_DROP_OPS", "").split(",") if k)
 
 # ------------------------------------------------------------------------------------------------
 # single-kernel emitters
