@@ -542,6 +542,9 @@ FF_FUSE = os.environ.get("RCDM_FF_FUSE", "1") != "0"
 # rcdm_rowchain (rowff.hip): [C x C projection (+ residual) -> LayerNorm (+ pe) -> q | qkv projection or feed-forward] as one
 # row-stationary launch.  RCDM_ROWCHAIN=0 keeps the separate launches (same-process A/B).
 ROW_CHAIN = os.environ.get("RCDM_ROWCHAIN", "1") != "0"
+# a chain launch is one block of 160 rows per CU: below ~3/4 of a chip's worth of rows (the 256x256 configuration has
+# 10240 token rows at this width = 64 blocks) the separate tile-parallel launches are faster
+CHAIN_MIN_ROWS = int(os.environ.get("RCDM_CHAIN_MIN_ROWS", str(160 * 192)))
 CHAIN_PROJ = os.environ.get("RCDM_CHAIN_PROJ", "1") != "0"   # proj_out + residual as the trailing stage of the feed-forward chain
 CHAIN_GN = os.environ.get("RCDM_CHAIN_GN", "1") != "0"   # GroupNorm apply in the prologue of the proj_in chain
 
@@ -572,7 +575,7 @@ def emit_rowchain(plan, a_in, res, tok, a_bias, ln, pe, stream, tail, out, rows_
 def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None):
     """x += FeedForward_geglu(LayerNorm(x))  (attention.py:514 / motion_module.py:243), in place on tok.
     stream: (fragment-major weight stream, packed b1) of Packer.ff_stream, or None for the unfused chain."""
-    if stream is not None:
+    if stream is not None and M >= CHAIN_MIN_ROWS:
         ws, b1p = stream
         d = hip.FFDesc(M, C, tok.ld, tok.ld, 1e-5)
 
@@ -604,13 +607,14 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
     # self-attention over the Lq tokens of each sequence.  pre = (rows, bias): tok = rows proj_in^T + bias has NOT been
     # emitted yet and rides in the chain launch with norm1 and the q | k | v projection
     qkv = plan.rows("qkv", M, 3 * C).rows(0, Ms)
+    big = M >= CHAIN_MIN_ROWS
     if pre is not None:
         emit_rowchain(plan, pre[0], None, tok, pre[1], w.ln[0], None, w.ch_in_qkv, 3, qkv, gn=pre[2])
     else:
         emit_layernorm(plan, tok.rows(0, Ms), w.ln[0][0], w.ln[0][1], a.rows(0, Ms))
         emit_gemm(plan, a.rows(0, Ms), w.qkv1, 3 * C, C, qkv, bias=w.qkv1_b)
     emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), ns, heads, Lq, Lq, d_head, ao.rows(0, Ms))
-    chain_q = w.has_cross and w.ch_o1_q is not None and not shared_half
+    chain_q = w.has_cross and w.ch_o1_q is not None and not shared_half and big
     if not chain_q:
         emit_gemm(plan, ao.rows(0, Ms), w.o1, C, C, tok.rows(0, Ms), bias=w.o1_b, residual=tok.rows(0, Ms), dup_rows=dup)
     if w.has_cross:
@@ -625,10 +629,10 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
             emit_xattn(plan, qc, ctx_img, n_seq, heads, Lq, L, d_head, ao)
         else:
             emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), n_seq, heads, Lq, L, d_head, ao)
-        if post is not None:         # ... and the transformer's proj_out + residual behind it: post = (stream, x, bias, out)
+        if post is not None and big:  # ... and the transformer's proj_out + residual behind it: post = (stream, x, bias, out)
             emit_rowchain(plan, ao, tok, tok, w.o2_b, w.ln[2], None, post[0], 2, post[3], b2=w.ff2_b, z=(post[1], post[2]))
             return
-        if w.ch_o2_ff is not None:   # attn2.to_out + residual -> norm3 -> ff -> + residual in one launch
+        if w.ch_o2_ff is not None and big:   # attn2.to_out + residual -> norm3 -> ff -> + residual in one launch
             emit_rowchain(plan, ao, tok, tok, w.o2_b, w.ln[2], None, w.ch_o2_ff, 0, tok, b2=w.ff2_b)
             return
         emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok)
@@ -650,7 +654,7 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     a = plan.rows("norm", g.M, C)
     tok = plan.rows("tok", g.M, C)
     pre = None
-    if w.ch_in_qkv is not None and not shared_half:
+    if w.ch_in_qkv is not None and not shared_half and g.M >= CHAIN_MIN_ROWS:
         if CHAIN_GN and g.hw % 16 == 0 and g.hw >= 160:   # the norm's apply rides too: only its statistics are launched
             pre = (x, w.proj_in_b, emit_groupnorm_stats(plan, x, n_s, g.hw, w.gn_g, w.gn_b, 1e-6, groups))
         else:
@@ -659,7 +663,8 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     else:
         emit_groupnorm(plan, x.rows(0, M_s), n_s, g.hw, w.gn_g, w.gn_b, 1e-6, False, a.rows(0, M_s), groups)
         emit_gemm(plan, a.rows(0, M_s), w.proj_in, C, C, tok.rows(0, M_s), bias=w.proj_in_b)
-    post = (w.ch_o2_ffz, x, w.proj_out_b, out) if getattr(w, "ch_o2_ffz", None) is not None and w.has_cross else None
+    post = (w.ch_o2_ffz, x, w.proj_out_b, out) if (getattr(w, "ch_o2_ffz", None) is not None and w.has_cross and
+                                                   g.M >= CHAIN_MIN_ROWS) else None
     emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img, pre=pre,
                      post=post)
     if post is None:
@@ -682,7 +687,7 @@ def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
     g, C = geo, w.C
     d_head = C // heads
     a = plan.rows("norm", g.M, C)
-    chained = w.chains is not None and not prior_state
+    chained = w.chains is not None and not prior_state and g.M >= CHAIN_MIN_ROWS
     gn = None
     if prior_state:
         emit_layernorm(plan, x, w.prior_g, w.prior_b, a)
