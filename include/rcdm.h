@@ -99,6 +99,10 @@ int rcdm_set_igemm_pingpong(int32_t on);
 /* debug: when non-NULL, every igemm block writes 4 int64 {start, end (s_memtime ticks), ticks spent in epilogues,
  * k-steps done} at trace[(blockIdx.y*gridDim.x + blockIdx.x)*4]; NULL (default) disables it. */
 int rcdm_debug_set_igemm_trace(void* device_buffer);
+/* debug, builds with -DRCDM_ATTN_TRACE only (tools/trace_attn.py): when non-NULL every wave of rcdm_flash_attn writes 8 int64 at
+ * trace[(block * waves + wave) * 8]: {loop ticks, ticks at the barrier + K/V staging, in the QK^T issue, in the softmax, in the PV
+ * issue, key tiles, 0, 0}.  The product build ignores the pointer. */
+int rcdm_debug_set_attn_trace(void* device_buffer);
 /* roofline calibration: `blocks` x 4 waves each run iters x 4 independent v_mfma_f32_32x32x16_f16 (32768 flop each) and
  * nothing else; ticks[block] (optional) = s_memtime ticks the first wave spent in its loop.  tools/mfma_peak.py */
 int rcdm_debug_mfma_peak(int32_t blocks, int32_t iters, float* sink, long long* ticks, void* stream);

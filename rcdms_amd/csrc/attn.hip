@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include "common.h"
 
+long long* g_attn_trace = nullptr;  // rcdm_debug_set_attn_trace (read by -DRCDM_ATTN_TRACE builds only)
+
 namespace {
 
 constexpr int KT = 64;        // keys per tile
@@ -31,6 +33,7 @@ struct AttnArgs {
   const unsigned char* kvalid;  // MASKED: [batch][Lk], 0 = key padded out (NULL = all valid)
   int causal;                   // MASKED: key k visible to query q only if k <= q
   int plain_order;              // RCDM_ATTN_XCD=0: blocks in plain (query block fastest) order, for A/B
+  long long* trace;             // -DRCDM_ATTN_TRACE builds (tools/trace_attn.py): per-wave s_memtime sums of the loop's phases
 };
 
 // V row stride in LDS (halfs) for 32*DF padded columns: the smallest >= 64*DF bytes whose dword stride is 16 or 48
@@ -233,8 +236,18 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p
   f32x16 s_even[QF][2], s_odd[PIPE ? QF : 1][2];
   if constexpr (PIPE) qk(0, s_even);
 
+#ifdef RCDM_ATTN_TRACE
+  long long tr_sync = 0, tr_qk = 0, tr_sm = 0, tr_pv = 0, tr_q;
+#define RCDM_ATTN_STAMP(acc_) do { const long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - tr_q; tr_q = n_; } while (0)
+  const long long tr_begin = __builtin_amdgcn_s_memtime();
+#else
+#define RCDM_ATTN_STAMP(acc_) do {} while (0)
+#endif
   auto step = [&](int kt, f32x16 (&sacc)[QF][2], f32x16 (&snext)[QF][2]) {  // !PIPE: snext aliases sacc, unused
     const int kbase = kt * KT, par = kt & 1;
+#ifdef RCDM_ATTN_TRACE
+    tr_q = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
     put_k(PIPE ? par : par ^ 1);  // PIPE: K(kt+2) over K(kt), last read in iteration kt-1; else K(kt+1)
     put_v(par ^ 1);   // V(kt+1): image `par^1` held V(kt-1), last read in iteration kt-1
@@ -243,12 +256,14 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p
     float m_next[QF];
 #pragma unroll
     for (int j = 0; j < QF; ++j) m_next[j] = m_sub[j];
+    RCDM_ATTN_STAMP(tr_sync);
     if constexpr (PIPE) {
       if (kt + 1 < ntiles) qk(par ^ 1, snext);
     } else {
       qk(par, sacc);  // d > 80: a second score set does not fit the register file
     }
 
+    RCDM_ATTN_STAMP(tr_qk);
     f16x8 pf[QF][4];
 #pragma unroll
     for (int j = 0; j < QF; ++j) {
@@ -357,6 +372,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p
 
     // ---- O^T += V^T P^T : 4 steps of 16 keys.  The A fragment (head-dim rows x 8 keys per lane) is two
     // transpose reads of the row-major V image: keys 16 st + 4 hi + {0..3} and + 8 + {0..3}, the order P holds.
+    RCDM_ATTN_STAMP(tr_sm);
 #pragma unroll
     for (int f = 0; f < DF; ++f)
 #pragma unroll
@@ -368,6 +384,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p
 #pragma unroll
         for (int j = 0; j < QF; ++j) oacc[j][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.v, pf[j][st], oacc[j][f], 0, 0, 0);
       }
+    RCDM_ATTN_STAMP(tr_pv);
   };
 
   if constexpr (PIPE) {
@@ -378,6 +395,12 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p
   } else {
     for (int kt = 0; kt < ntiles; ++kt) step(kt, s_even, s_even);
   }
+#ifdef RCDM_ATTN_TRACE
+  if (p.trace && lane == 0) {
+    long long* o = p.trace + ((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 8;
+    o[0] = __builtin_amdgcn_s_memtime() - tr_begin; o[1] = tr_sync; o[2] = tr_qk; o[3] = tr_sm; o[4] = tr_pv; o[5] = ntiles;
+  }
+#endif
 
 #pragma unroll
   for (int j = 0; j < QF; ++j) {
@@ -772,6 +795,7 @@ int rcdm_flash_attn_masked(const rcdm_attn_desc* d, const void* Q, const void* K
   a.c = d->scale * 1.4426950408889634f;
   a.kvalid = key_valid;
   a.causal = causal ? 1 : 0;
+  a.trace = g_attn_trace;
   hipStream_t stream = (hipStream_t)stream_;
   const int ds = (d->d + 15) / 16;
   if (ds <= 1) return launch_flash<1>(a, stream);
@@ -779,6 +803,11 @@ int rcdm_flash_attn_masked(const rcdm_attn_desc* d, const void* Q, const void* K
   if (ds <= 3) return launch_flash<3>(a, stream);
   if (ds <= 5) return launch_flash<5>(a, stream);
   return launch_flash<10>(a, stream);
+}
+
+int rcdm_debug_set_attn_trace(void* device_buffer) {
+  g_attn_trace = (long long*)device_buffer;
+  return RCDM_OK;
 }
 
 int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const void* V, void* out, void* stream_) {

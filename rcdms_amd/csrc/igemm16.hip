@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
     if (g + 1 < nkl) issue(g + 1, (g + 1) & 1);
 #endif
     const char* sb = smem + (g & 1) * STAGE;
+#if RCDM_PRIO_LOADS   // everything but the MFMA runs of a k-step at raised priority (see igemm8.hip compute())
+    __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int koff = kk ? koff1 : koff0;
@@ -151,10 +154,16 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
       for (int i = 0; i < FN; ++i) wf[i] = *(const f16x8*)(sb + rowB + i * 2048 + koff);
 #pragma unroll
       for (int j = 0; j < FM; ++j) xf[j] = *(const f16x8*)(sb + rowA + j * 2048 + koff);
+#if RCDM_PRIO_LOADS
+      __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
       for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#if RCDM_PRIO_LOADS
+      __builtin_amdgcn_s_setprio(3);
+#endif
     }
   }
   wait_lgkm0();

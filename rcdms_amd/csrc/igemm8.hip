@@ -222,14 +222,23 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
   };
   auto compute = [&]() __attribute__((always_inline)) {
     if (no_mfma) return;
-#ifndef RCDM_PP_NOPRIO
+    // The MFMA run at LOW priority, everything else of this wave (the load phases: address arithmetic, ds_read, DMA issue)
+    // at high priority.  The SIMD issues oldest-first among equal priorities, and a wave whose next MFMA waits for the
+    // matrix pipe keeps the other wave's VALU instructions from issuing (tools/ubench/pipe_overlap.hip: a VALU wave beside
+    // two MFMA-streaming waves gets one instruction per 23 clocks at equal priority, one per 6.4 at s_setprio 3, with the
+    // MFMA rate unchanged).  Round 2 had it the other way round (MFMA run at priority 1); -0.05 ms per step.
+#if RCDM_PRIO_LOADS
+    __builtin_amdgcn_s_setprio(0);
+#else
     __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
     for (int i = 0; i < FNW; ++i)
 #pragma unroll
       for (int j = 0; j < FMW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-#ifndef RCDM_PP_NOPRIO
+#if RCDM_PRIO_LOADS
+    __builtin_amdgcn_s_setprio(3);
+#else
     __builtin_amdgcn_s_setprio(0);
 #endif
   };

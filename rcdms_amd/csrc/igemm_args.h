@@ -5,6 +5,9 @@
 #include "common.h"
 
 constexpr int BK = 64;
+#ifndef RCDM_PRIO_LOADS
+#define RCDM_PRIO_LOADS 1   // 0: round-2 priorities (MFMA runs of the ping-pong kernel at s_setprio 1, nothing else raised), for A/B builds
+#endif
 
 struct IgemmArgs {
   const f16* A;

@@ -13,6 +13,9 @@ __device__ __forceinline__ void epi_store16(f16* dst, uint4 v) { *(uint4*)dst = 
 template <int FMW, int FNW, bool SLAB, int NT, int BM, int BN, bool LN_OK = false>
 __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f32x4 (&acc)[FNW][FMW], int cm0, int cn0,
                                               int row0, int col0, int l15, int kg, int t) {
+#if RCDM_PRIO_LOADS   // the epilogue's VALU work at raised priority against the co-resident block's MFMA runs
+  __builtin_amdgcn_s_setprio(3);
+#endif
   if constexpr (SLAB) {
     // ---- split-K: the fp32 tile goes to this split's slab (16 B per lane, 64-B runs per pixel row); bias / row
     // vector / residual / GEGLU belong to splitk_reduce_kernel

@@ -84,6 +84,7 @@ SYMBOLS = {
     "rcdm_set_igemm_variant": (C.c_int, [_I]),
     "rcdm_set_igemm_pingpong": (C.c_int, [_I]),
     "rcdm_debug_set_igemm_trace": (C.c_int, [_P]),
+    "rcdm_debug_set_attn_trace": (C.c_int, [_P]),
     "rcdm_debug_mfma_peak": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P]),
     "rcdm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_conv3x3_workspace_bytes": (_SZ, [C.POINTER(ConvDesc)]),
