@@ -66,40 +66,32 @@ def build_model(device):
     return m
 
 
-def cpu_baseline(model, latent, ctx_len, ddim_steps, budget_s=25.0):
-    """Oracle (CPU fp32 restatement of the reference, kind "port") on this box's host cores, BOUNDED: one UNet call of
-    the 50 at 32x32 latents first (2.556 TFLOP); if the FLOP-scaled estimate of the real 64x64 call fits 1.8 x budget_s it is
-    timed directly, otherwise its time is extrapolated by the algorithmic-FLOP ratio 11.044 / 2.556 (said in `sample`).
+def cpu_baseline(model, latent, ctx_len, ddim_steps, budget_s=200.0):
+    """Oracle (CPU fp32 restatement of the reference, kind "port") on this box's host cores, per BASELINE.md section 3:
+    one warm-up UNet call at the REAL size (b=2, f=5, latent x latent, L=ctx_len), then up to 3 timed calls of the same;
+    the median is reported and extrapolated x ddim_steps (a full 50-step CPU story is most of an hour).  Bounded: when the
+    warm-up shows that three more calls do not fit budget_s, fewer are timed (at least one) and `sample` says how many.
     torch CPU scales badly past a few dozen threads, so at most 64 are used; `cores` reports the threads used."""
     from oracle import unet_oracle as O
     from rcdms_amd import synth
     threads = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    st = synth.synthetic_story(stories=1, latent_hw=(latent, latent), ctx_len=ctx_len, seed=42)
+    x = torch.cat([torch.cat([st["latents"]] * 2), st["mask"], st["masked_latents"]], dim=1)
 
-    def one_call(hw):
-        st = synth.synthetic_story(stories=1, latent_hw=(hw, hw), ctx_len=ctx_len, seed=42)
-        x = torch.cat([torch.cat([st["latents"]] * 2), st["mask"], st["masked_latents"]], dim=1)
+    def one_call():
         t0 = time.time()
         with torch.no_grad():
             O.unet_forward(sd, O.SD15_STAGE2_CONFIG, x, torch.tensor(981), st["ctx"])
         return time.time() - t0
 
-    # median of 3 calls at 32x32 latents (BASELINE.md section 3: median of >= 3; three 64x64 calls would be ~100 s of CPU
-    # work, beyond the bounded sample this leg is allowed), then ONE 64x64 call timed directly
-    t32s = sorted(one_call(32) for _ in range(3))
-    t32 = t32s[1]
-    spread = f"32x32 probe: median of 3 = {t32:.1f} s, min {t32s[0]:.1f}, max {t32s[2]:.1f}"
-    if latent == 64 and t32 * ALGO_TFLOP_PER_CALL[64] / ALGO_TFLOP_PER_CALL[32] < 1.8 * budget_s:
-        t_call = one_call(64)
-        how = f"1 UNet call of the {ddim_steps} per story at 64x64 latents timed directly ({t_call:.1f} s; {spread})"
-    elif latent == 64:
-        t_call = t32 * ALGO_TFLOP_PER_CALL[64] / ALGO_TFLOP_PER_CALL[32]
-        how = (f"UNet call at 32x32 latents ({spread}) scaled by the algorithmic-FLOP ratio 11.044/2.556 to the "
-               f"64x64 call ({t_call:.1f} s)")
-    else:
-        t_call = t32 if latent == 32 else one_call(latent)
-        how = f"1 UNet call at {latent}x{latent} latents ({t_call:.1f} s; {spread})"
+    warm = one_call()
+    n = max(1, min(3, int((budget_s - warm) / max(warm, 1e-3))))
+    ts = sorted(one_call() for _ in range(n))
+    t_call = ts[len(ts) // 2] if n % 2 else 0.5 * (ts[n // 2 - 1] + ts[n // 2])
+    how = (f"1 warm-up ({warm:.1f} s) + {n} timed UNet calls of the {ddim_steps} per story at {latent}x{latent} latents: "
+           f"median {t_call:.1f} s, min {ts[0]:.1f}, max {ts[-1]:.1f}")
     fps = 5.0 / (ddim_steps * t_call)
     return {"value": fps, "unit": "story-frames/s", "cores": threads, "kind": "port",
             "sample": how + f"; b=2 f=5 L={ctx_len}, fp32 torch CPU restatement, extrapolated x{ddim_steps} steps"}
@@ -237,7 +229,8 @@ def main(argv=None):
                               "unit": "story-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                               "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "none", "data": "stub",
-                              "per_rank_ms": [round(1e3 * x / a.steps, 3) for x in per_rank]}), flush=True)
+                              "per_rank_ms": [round(1e3 * x / a.steps, 3) for x in per_rank],
+                              "devices": [f"rank{r}:cpu" for r in range(world)]}), flush=True)
         if dist_on:
             dist.destroy_process_group()
         return
@@ -266,7 +259,8 @@ def main(argv=None):
     model = build_model(dev)
     if dist_on:
         from rcdms_amd.dist import broadcast_module
-        broadcast_module(model, src=0)  # RCCL over xGMI: every replica holds rank 0's weights
+        # RCCL over xGMI: every replica holds rank 0's weights; matrices travel as f16 (what the kernels consume): 2.55 GB
+        broadcast_module(model, src=0, wire_dtype=torch.float16)
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
     S, T = a.stories, a.ddim_steps
     story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42 + rank)
@@ -340,6 +334,17 @@ def main(argv=None):
         "per_rank_ms": [round(1e3 * x / a.steps, 3) for x in per_rank],
         "roofline": roof,
     }
+    if dist_on:
+        # what the communicator actually spanned: one entry per rank (device index, name, uuid tail), and the RCCL version
+        props = torch.cuda.get_device_properties(dev)
+        mine = f"rank{rank}:cuda{local_rank}:{props.name}:{str(getattr(props, 'uuid', ''))[-8:]}"
+        names = [None] * world
+        dist.all_gather_object(names, mine)
+        out["devices"] = names
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            out["rccl_version"] = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, a.latent, a.ctx_len, T)
     if rank == 0:

@@ -4,6 +4,7 @@ with procedural name-seeded weights (rcdms_amd/synth.py).  Run in the build cont
 
     python -m oracle.make_golden [--full] [--only blocks|tiny|ctx|prior|full]   # --full adds the full-width UNet (32x32, 64x64)
     python -m oracle.make_golden --only loop32|loop64|cfg3     # reference-UNet-driven DDIM trajectories / config-3 story
+    python -m oracle.make_golden --only eps32|eps64            # reference eps at stored trajectory points x_k (mid / late steps)
 
 What is stored: small inputs and the reference outputs (fp32 .npz), plus a digest of the reference's
 state-dict key/shape list so the mirrored classes are checked to have the identical 1286-key layout.
@@ -208,6 +209,36 @@ def loop_trajectory(hw, steps):
     O.denoise_loop(None, None, s["latents"], s["mask"], s["masked_latents"], s["ctx"], steps, 2.0, unet=unet, callback=cb)
 
 
+EPS_AT = {32: (5, 10, 19), 64: (10, 30, 49)}
+
+
+@torch.no_grad()
+def eps_along_trajectory(hw):
+    """The reference UNet's raw output eps at points x_k of the stored reference trajectory (loop_full_<hw>.npz), k in the
+    middle and at the end of the loop, where |x| has grown ~20x over x_0 (the f16 headroom case VERDICT r3 asks for).  The
+    UNet input at loop index k is cat([x_k]*2, mask, masked) at t_k = timesteps[k] (RCDMs_pipeline.py:455-476)."""
+    from oracle import unet_oracle as O
+    g = np.load(os.path.join(GOLD, f"loop_full_{hw}.npz"))
+    m = ref_scaffold.build_reference_unet()
+    dig = load_procedural(m, seed=0)
+    assert dig == str(g["digest"])
+    s = synth.synthetic_story(stories=1, latent_hw=(hw, hw), ctx_len=85, seed=42)
+    sched = O.DDIMOracle()
+    sched.set_timesteps(int(g["steps"]))
+    out = {}
+    for k in EPS_AT[hw]:
+        xk = torch.from_numpy(g[f"x{k}"])
+        t = int(sched.timesteps[k])
+        x = torch.cat([torch.cat([xk] * 2), s["mask"], s["masked_latents"]], dim=1)
+        t0 = time.time()
+        y = m(x, torch.tensor(t), encoder_hidden_states=s["ctx"], return_dict=False)[0]
+        print("  reference eps at k=%d t=%d: |x| rms %.3f, |eps| rms %.3f max %.3f  (%.0f s)"
+              % (k, t, xk.pow(2).mean().sqrt(), y.pow(2).mean().sqrt(), y.abs().max(), time.time() - t0), flush=True)
+        out[f"eps{k}"] = y
+        out[f"t{k}"] = np.int64(t)
+    save(f"eps_full_{hw}", ks=np.array(EPS_AT[hw], dtype=np.int64), digest=dig, **out)
+
+
 @torch.no_grad()
 def config3_story():
     """BASELINE config 3 (FlintstonesSV, L = 91, 4 stories = b 8, 64x64 latents): the reference UNet run on ONE story
@@ -283,3 +314,5 @@ if __name__ == "__main__":
         print("config-2 trajectory"); loop_trajectory(64, 50)
     if a.only == "cfg3":
         print("config-3 story"); config3_story()
+    if a.only in ("eps32", "eps64"):
+        print("eps along the trajectory"); eps_along_trajectory(int(a.only[3:]))

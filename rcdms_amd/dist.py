@@ -26,31 +26,55 @@ def split_stories(n_stories, world_size):
     return out
 
 
-def broadcast_module(module, src=0, bucket_bytes=256 << 20):
+def broadcast_module(module, src=0, bucket_bytes=256 << 20, wire_dtype=None):
     """Broadcast every parameter and buffer of `module` from rank `src`, coalesced into flat buckets so that the
-    ring over point-to-point xGMI links moves a few large messages instead of 1286 small ones."""
+    ring over point-to-point xGMI links moves a few large messages instead of 1286 small ones.  ONE flat staging
+    buffer per dtype is allocated (bucket_bytes, or the largest single tensor) and reused by every bucket: tensors are
+    copied into it, broadcast, copied out — no per-bucket torch.cat allocation on any rank.
+    wire_dtype (e.g. torch.float16): floating tensors with >= 2 dims (the weight matrices, 99.9 % of the bytes) travel in
+    that dtype — half the bytes over xGMI for fp32 masters.  The kernels consume exactly f16(weight) (Packer.mat_f16), so
+    the launch plans built on every rank are bit-identical to rank `src`'s; `src` rounds its own masters the same way so
+    that all replicas' state dicts are equal too.  Vectors (biases, norm scales: consumed in fp32) always travel as stored."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     tensors = [t for t in module.state_dict().values() if torch.is_tensor(t)]
     by_dtype = {}
     for t in tensors:
-        by_dtype.setdefault(t.dtype, []).append(t)
-    for dtype, group in by_dtype.items():
-        bucket, size = [], 0
-        for t in group + [None]:
-            if t is not None:
-                bucket.append(t)
-                size += t.numel() * t.element_size()
-            if bucket and (t is None or size >= bucket_bytes):
-                flat = torch.cat([b.detach().reshape(-1) for b in bucket])
-                dist.broadcast(flat, src=src)
-                off = 0
+        wire = t.dtype
+        if wire_dtype is not None and t.is_floating_point() and t.dim() >= 2 and t.element_size() > torch.empty(0, dtype=wire_dtype).element_size():
+            wire = wire_dtype
+        by_dtype.setdefault((wire, t.device), []).append(t)
+    for (wire, device), group in by_dtype.items():
+        esz = torch.empty(0, dtype=wire).element_size()
+        cap = max(max(t.numel() for t in group), max(1, bucket_bytes // esz))
+        flat = torch.empty(cap, dtype=wire, device=device)
+        bucket, fill = [], 0
+
+        def flush():
+            nonlocal bucket, fill
+            if not bucket:
+                return
+            view = flat[:fill]
+            dist.broadcast(view, src=src)
+            off = 0
+            with torch.no_grad():
                 for b in bucket:
                     n = b.numel()
-                    with torch.no_grad():
-                        b.copy_(flat[off:off + n].view_as(b))
+                    b.copy_(view[off:off + n].view_as(b))     # receivers: the payload; src: its own (possibly rounded) copy
                     off += n
-                bucket, size = [], 0
+            bucket, fill = [], 0
+
+        for t in group:
+            n = t.numel()
+            if fill + n > cap:
+                flush()
+            with torch.no_grad():
+                flat[fill:fill + n].copy_(t.detach().reshape(-1))
+            bucket.append(t)
+            fill += n
+            if fill * esz >= bucket_bytes:
+                flush()
+        flush()
     if hasattr(module, "_programs"):
         module._programs = {}
 

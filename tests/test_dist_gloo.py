@@ -83,6 +83,74 @@ def test_bench_gpus_flag_spawns_ranks_world2():
     assert abs(out["value"] - 5 * 3 * 2 / (out["ms_per_step"] * 3e-3)) < 1e-4 * out["value"]
 
 
+def test_bench_gpus_flag_spawns_ranks_world8():
+    """The form the driver's 8-GPU scaling run takes (`bench.py --gpus 8`): eight ranks come up through
+    torch.distributed.run, rendezvous on 127.0.0.1, pass the barriers, and the line reports the slowest rank (rank 7
+    sleeps 160 ms per pass) with one per_rank / devices entry per rank."""
+    import json
+    r = _run_bench("--gpus", "8", "--stub-cpu", "--steps", "2", timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 8 and len(out["per_rank_ms"]) == 8 and len(out["devices"]) == 8
+    assert out["ms_per_step"] >= 159.0, out
+    assert abs(out["value"] - 5 * 2 * 8 / (out["ms_per_step"] * 2e-3)) < 1e-4 * out["value"]
+
+
+def _unet_worker(rank, world, port, q):
+    """broadcast_module on the REAL UNet3DConditionModel parameter list (full stage-2 topology at width 32, CPU): 1286-key
+    state dict, fp32 matrices + vectors + the motion modules' positional-encoding buffers, several buckets, f16 wire."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from src.models.unet import UNet3DConditionModel
+        mk = dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
+                  temporal_position_encoding=True, temporal_position_encoding_max_len=5, temporal_attention_dim_div=1)
+        with torch.device("meta"):
+            m = UNet3DConditionModel(in_channels=9, cross_attention_dim=64, block_out_channels=(32, 64, 128, 128),
+                                     use_motion_module=True, motion_module_resolutions=[1, 2, 4, 8],
+                                     unet_use_cross_frame_attention=False, unet_use_temporal_attention=False,
+                                     motion_module_type="Vanilla", motion_module_kwargs=mk)
+        m = m.to_empty(device="cpu")
+        g = torch.Generator().manual_seed(500 + rank)               # different weights per rank before the broadcast
+        with torch.no_grad():
+            for t in m.state_dict().values():
+                t.copy_(torch.randn(t.shape, generator=g))
+        m._programs = {"stale": object()}                            # a launch plan built from the old weights
+        sd = m.state_dict()
+        n_keys = len(sd)
+        before = {k: v.clone() for k, v in sd.items()} if rank == 0 else None
+        broadcast_module(m, src=0, bucket_bytes=1 << 20, wire_dtype=torch.float16 if world == 2 else None)
+        sd = m.state_dict()
+        digest = torch.cat([t.reshape(-1).double() for t in sd.values()]).sum().item()
+        ok_round = True
+        if rank == 0:    # src holds f16-rounded matrices and untouched vectors afterwards
+            for k, v in sd.items():
+                want = before[k].half().float() if before[k].dim() >= 2 else before[k]
+                ok_round &= torch.equal(v, want)
+        q.put((rank, n_keys, digest, m._programs == {}, ok_round))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_real_unet_state_dict_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unet_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, n0, d0, inv0, ok0), (r1, n1, d1, inv1, ok1) = res
+    assert n0 == n1 == 1286, (n0, n1)
+    assert d0 == d1, "weights differ after broadcast"
+    assert inv0 and inv1, "cached launch plans must be dropped when the weights change"
+    assert ok0 and ok1
+
+
 def test_bench_refuses_more_ranks_than_devices():
     """On a box with fewer devices than --gpus the bench must fail loudly, never print n_gpus from fewer devices."""
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
