@@ -347,6 +347,8 @@ def main(argv=None):
             out["rccl_version"] = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, a.latent, a.ctx_len, T)
+    if os.environ.get("RCDM_DROP_OPS"):
+        out["data"] = "INVALID (RCDM_DROP_OPS set: ops left out of the plan, timing experiment only)"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -185,6 +185,9 @@ int rcdm_layernorm(const rcdm_layernorm_desc* d, const void* x, const float* gam
  *   self-attention over the hw latent patches of one frame and cross-attention over the L_text
  *   context rows of that frame.  Q rows [batch*Lq][ldq] with head h at columns [h*d, (h+1)*d);
  *   K,V rows [batch*Lk][ldk|ldv]; out [batch*Lq][ldo].  d % 8 == 0, d <= 160.
+ *   Range: scaled scores |scale * log2(e) * q.k| < 2^15 (the d = 40, Lk >= 256 kernel keeps its running max as an f16 inside
+ *   the Q fragment and re-rounds Q * scale * log2(e) to f16: relative error ln2 * 2^-12 * |scaled score| on a probability;
+ *   environment RCDM_ATTN_MSUB=0 selects the fp32-fma softmax instead, which has neither limit).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   int32_t batch, heads, Lq, Lk, d;
@@ -268,7 +271,12 @@ int rcdm_ff_fused(const rcdm_ff_desc* d, const void* x, const float* ln_gamma, c
  *     attn2.to_out[0] / attention_blocks[-1].to_out[0] + hidden_states -> norm3 / ff_norm -> ff -> + hidden_states  (tail 0)
  *   W_a = fp32 [C][C] (nn.Linear layout).  The weights come as one fragment-major stream (rcdm_pack_rowchain,
  *   rcdm_rowchain_stream_bytes); b1_packed / b2 only with tail 0.  tok may alias res, out may alias tok (tail 0) — a block
- *   reads and writes only its own rows.  Supported C: rcdm_rowchain_supported.
+ *   reads and writes only its own rows.  Supported C: rcdm_rowchain_supported; supported (C, tail, pe) combinations:
+ *   rcdm_rowchain_config_supported — pe (with rows_per_frame, frames <= 8) rides with tail 1 / 3 only: with the feed-forward
+ *   tails the per-block parameter region (up to 19 C floats) would not fit the 160 KB of LDS (RCDM_ESHAPE).
+ *   Preconditions (RCDM_EINVAL / RCDM_ESHAPE when violated): every pointer 16-byte aligned (the fp32 vectors a_bias, ln_*,
+ *   pe, b1_packed, b2, z_bias, gn_* are fetched as float4, the rows as 16-byte pieces), and M * ld * 2 < 2^31 for every row
+ *   operand (32-bit byte offsets into 2-GB buffer resources).  The same two rules hold for rcdm_ff_fused.
  *   gn_stat != NULL (only with res == NULL): a_in is the RAW input of the GroupNorm in front of proj_in and the kernel
  *   applies  a_in[m][c] * rstd * gn_gamma[c] + (gn_beta[c] - mean * rstd * gn_gamma[c])  (rounded to f16 like the separate
  *   launch) with (mean, rstd) = gn_stat[m / gn_rows][c / (C / gn_groups)] from rcdm_groupnorm_stats; gn_rows % 16 == 0,
@@ -284,6 +292,7 @@ typedef struct {
   int32_t ldz;                     /* row stride of z_res (tail 2) */
 } rcdm_rowchain_desc;
 int rcdm_rowchain_supported(int32_t C);
+int rcdm_rowchain_config_supported(int32_t C, int32_t tail, int32_t pe_frames);   /* pe_frames = 0: no pe */
 size_t rcdm_rowchain_stream_bytes(int32_t C, int32_t tail);
 /* wa [C][C]; tail 1 / 3: wt [tail*C][C]; tail 0 / 2: w1 [8C][C], b1 [8C], w2 [C][4C] and b1_packed [8C] (out); tail 2: wt [C][C] */
 int rcdm_pack_rowchain(const float* wa, int32_t C, int32_t tail, const float* wt, const float* w1, const float* b1,

@@ -70,6 +70,11 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // the (per query, usually zero) difference is added only in tiles where some query's max moved — and it moves rarely,
 // because the running max is only raised when a tile exceeds it by more than 2^MSUB_THR (deferred rescale: P <= 64 in
 // f16, row sums and O in fp32).  Whatever value of m is used cancels in O / l, its f16 rounding included.
+// Range: m lives in an f16 (the Q fragment), whose spacing is 2^(e-10) at magnitude 2^e, so P <= 2^(THR + ulp(m) / 2): 2^7 at
+// |m| < 4096, 2^14 at |m| < 32768 — finite in f16 for every |scaled score| < 2^15 (documented in rcdm.h; beyond that the
+// softmax is one-hot to ~10^4 digits and the caller's scale is wrong).  Accuracy: Q * c is re-rounded to f16, a relative
+// 2^-12 on every score, i.e. a relative ln2 * 2^-12 * |score| on P (1 % at |score| = 50): tests/test_hip_kernels.py::
+// test_flash_attn_msub_large_logits measures it against the fp32 oracle; RCDM_ATTN_MSUB=0 selects the fma-path kernel.
 constexpr float MSUB_THR = 6.0f;
 
 template <int DS, int QF, bool PIPE, bool MASKED, int NW, int MD = 0>  // MD: MSUB with head dim MD (0: off); d padded to 16*DS for QK^T and to 32*DF for PV; a wave owns QF fragments of 32 queries

@@ -646,12 +646,27 @@ inline unsigned grid_for(size_t n) {
   return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+// preconditions the kernels do not check themselves: per-column fp32 vectors are fetched as aligned float4, and row offsets
+// are 32-bit byte offsets into a 2-GB buffer resource
+inline bool misaligned16(const void* p) { return p && ((uintptr_t)p & 15); }
+inline bool rows_overflow(int M, int ld) { return (size_t)M * (size_t)ld * 2 >= 0x7FFFFFFFull; }
+
 }  // namespace
 
 extern "C" {
 
 int rcdm_ff_fused_supported(int32_t C) { return C == 320 ? 1 : 0; }
 int rcdm_rowchain_supported(int32_t C) { return C == 320 ? 1 : 0; }
+
+// whether rcdm_rowchain has a launch for this configuration: width, tail, frames of the positional-encoding table (0 = no
+// pe).  pe rides with tail 1 / 3 only (with the feed-forward tails the parameter region would not fit the 160 KB of LDS)
+// and for at most 8 frames.
+int rcdm_rowchain_config_supported(int32_t C, int32_t tail, int32_t pe_frames) {
+  if (C != 320 || tail < 0 || tail > 3) return 0;
+  if (pe_frames < 0 || pe_frames > 8) return 0;
+  if (pe_frames > 0 && (tail == 0 || tail == 2)) return 0;
+  return 1;
+}
 
 size_t rcdm_ff_stream_bytes(int32_t C) { return C > 0 ? (size_t)24 * C * C : 0; }
 
@@ -694,6 +709,10 @@ int rcdm_ff_fused(const rcdm_ff_desc* d, const void* x, const float* ln_gamma, c
   if (!d || !x || !ln_gamma || !ln_beta || !wstream || !b1_packed || !b2 || !out) return RCDM_EINVAL;
   if (d->M <= 0 || d->ldx < d->C || d->ldo < d->C || (d->ldx & 7) || (d->ldo & 7)) return RCDM_EINVAL;
   if (d->C != 320) return RCDM_ESHAPE;
+  if (misaligned16(ln_gamma) || misaligned16(ln_beta) || misaligned16(b1_packed) || misaligned16(b2) || misaligned16(x) ||
+      misaligned16(out) || misaligned16(wstream))
+    return RCDM_EINVAL;
+  if (rows_overflow(d->M, d->ldx) || rows_overflow(d->M, d->ldo)) return RCDM_ESHAPE;
   RowArgs a{};
   a.a_in = (const f16*)x; a.out = (f16*)out; a.wstream = (const f16*)wstream;
   a.ln_g = ln_gamma; a.ln_b = ln_beta; a.b1p = b1_packed; a.b2 = b2;
@@ -712,6 +731,14 @@ int rcdm_rowchain(const rcdm_rowchain_desc* d, const void* a_in, const void* res
   if (pe && (d->rows_per_frame <= 0 || d->frames <= 0 || d->frames > 8)) return RCDM_EINVAL;
   if ((d->tail == 0 || d->tail == 2) && (!b1_packed || !b2)) return RCDM_EINVAL;
   if (d->C != 320 || d->tail < 0 || d->tail > 3) return RCDM_ESHAPE;
+  if (!rcdm_rowchain_config_supported(d->C, d->tail, pe ? d->frames : 0)) return RCDM_ESHAPE;
+  if (misaligned16(a_bias) || misaligned16(ln_gamma) || misaligned16(ln_beta) || misaligned16(pe) || misaligned16(b1_packed) ||
+      misaligned16(b2) || misaligned16(z_bias) || misaligned16(gn_gamma) || misaligned16(gn_beta) || misaligned16(a_in) ||
+      misaligned16(res) || misaligned16(tok) || misaligned16(out) || misaligned16(z_res) || misaligned16(wstream))
+    return RCDM_EINVAL;
+  if (rows_overflow(d->M, d->lda) || rows_overflow(d->M, d->ldt) || rows_overflow(d->M, d->ldo) ||
+      (res && rows_overflow(d->M, d->ldr)) || (z_res && rows_overflow(d->M, d->ldz)))
+    return RCDM_ESHAPE;
   if (d->tail == 2) {   // feed-forward + trailing projection: the form the engine uses (stage-A residual, no pe)
     if (!res || pe || !z_res || !z_bias || d->ldz < d->C || (d->ldz & 7)) return RCDM_EINVAL;
   }

@@ -109,6 +109,10 @@ class Plan:
 # upper bound of a fusion before it is built: RCDM_DROP_OPS=layernorm,temporal_attn,... leaves every op of those kinds out of
 # the launch plan (wrong results; tools/ab_env.sh RCDM_DROP_OPS "" layernorm gives what removing all of them could buy at most)
 _DROP = frozenset(k for k in os.environ.get("RCDM_DROP_OPS", "").split(",") if k)
+if _DROP:
+    import sys
+    print(f"[rcdms_amd] WARNING: RCDM_DROP_OPS={','.join(sorted(_DROP))} — these op kinds are LEFT OUT of every launch plan; "
+          "results are garbage (timing experiments only)", file=sys.stderr, flush=True)
 
 # ------------------------------------------------------------------------------------------------
 # single-kernel emitters
@@ -137,11 +141,14 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
     def op():
         hip.gemm(d, A.ptr, Wt.data_ptr(), bptr, (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0,
                  residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
+    n_before = len(plan.ops)
     plan.add(op, f"gemm M={A.M} N={N} K={K} epi={epi}")
     plan.keep += [Wt, bias, rv_t]
     plan.n_launch += 2 if wsb else 1
     # a LayerNorm of exactly these output rows emitted NEXT can ride in this GEMM's epilogue (emit_layernorm)
     plan.last_gemm = None
+    if len(plan.ops) == n_before:   # the op was left out (RCDM_DROP_OPS): nothing for a following LayerNorm to replace
+        return
     if (LN_FUSE and N <= LN_FUSE_MAX_N and A.M >= LN_FUSE_MIN_M and not (geglu or gelu or rowvec) and split_k <= 1 and not wsb):
         plan.last_gemm = dict(n_ops=len(plan.ops), d=d, A=A, Wt=Wt, bptr=bptr, residual=residual, out=out, N=N, K=K, epi=epi)
 
@@ -687,7 +694,8 @@ def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
     g, C = geo, w.C
     d_head = C // heads
     a = plan.rows("norm", g.M, C)
-    chained = w.chains is not None and not prior_state and g.M >= CHAIN_MIN_ROWS
+    chained = (w.chains is not None and not prior_state and g.M >= CHAIN_MIN_ROWS and
+               hip.rowchain_config_supported(C, 3, g.f))   # pe table of g.f frames in the tail-3 chains
     gn = None
     if prior_state:
         emit_layernorm(plan, x, w.prior_g, w.prior_b, a)

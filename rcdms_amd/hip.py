@@ -102,6 +102,7 @@ SYMBOLS = {
     "rcdm_pack_ff_stream": (C.c_int, [_P, _P, _P, _I, _P, _P, _P]),
     "rcdm_ff_fused": (C.c_int, [C.POINTER(FFDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "rcdm_rowchain_supported": (C.c_int, [_I]),
+    "rcdm_rowchain_config_supported": (C.c_int, [_I, _I, _I]),
     "rcdm_rowchain_stream_bytes": (_SZ, [_I, _I]),
     "rcdm_pack_rowchain": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "rcdm_rowchain": (C.c_int, [C.POINTER(RowChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -263,6 +264,10 @@ def ff_fused_supported(Cc):
 
 def rowchain_supported(Cc):
     return bool(load().rcdm_rowchain_supported(Cc))
+
+
+def rowchain_config_supported(Cc, tail, pe_frames=0):
+    return bool(load().rcdm_rowchain_config_supported(Cc, tail, pe_frames))
 
 
 def rowchain_stream_bytes(Cc, tail):

@@ -47,7 +47,7 @@ def rows_to_5d(rows, b, c, f, h, w):
 
 
 def ws(nbytes):
-    return torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)   # split-K counters (first 16 KiB) start at zero
+    return torch.full((max(int(nbytes), 16),), 0xFF, dtype=torch.uint8, device=DEV)   # NaN-filled: no kernel may depend on workspace contents
 
 
 # ------------------------------------------------------------------------------------------------
@@ -571,6 +571,36 @@ def test_flash_attn_deferred_max_long_keys(hiplib, L, boost):
         outs.append(out)
     close(outs[0].reshape(1, L, C), ref)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("gain", [6.0, 30.0])
+def test_flash_attn_msub_large_logits(hiplib, gain):
+    """Large scaled scores through the d = 40 MSUB kernel (running max held as f16 inside the Q fragment, Q pre-scaled and
+    re-rounded to f16): q, k scaled so that |scale * log2(e) * q.k| reaches ~50 (gain 6) and ~1300 (gain 30, softmax nearly
+    one-hot).  Documented range of the kernel: |scaled score| < 2^15 (rcdm.h).  No inf / NaN, and the output stays within
+    the stated tolerance of the fp32 oracle on the same f16 inputs; the fma-path kernel (RCDM_ATTN_MSUB=0) has no such
+    re-rounding, so the measured difference between the two is printed."""
+    from rcdms_amd import hip
+    L, heads, d = 1024, 2, 40
+    C = heads * d
+    g = torch.Generator().manual_seed(77)
+    q = h16(torch.randn(1, L, C, generator=g) * gain ** 0.5)
+    k = h16(torch.randn(1, L, C, generator=g) * gain ** 0.5)
+    v = h16(torch.randn(1, L, C, generator=g))
+    ref = O.attention_core(q, k, v, heads)
+    qd, kd, vd = (t.reshape(-1, C).half().to(DEV) for t in (q, k, v))
+    out = torch.empty(L, C, dtype=torch.float16, device=DEV)
+    desc = hip.AttnDesc(1, heads, L, L, d, C, C, C, C, d ** -0.5)
+    hip.flash_attn(desc, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.float().cpu().reshape(1, L, C)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    smax = (torch.einsum("blhd,bmhd->bhlm", q.view(1, L, heads, d), k.view(1, L, heads, d)).abs().max() * d ** -0.5 * 1.4427).item()
+    print(f"gain {gain}: max |scaled score| {smax:.0f}, max abs err {err:.3e} (|ref| max {ref.abs().max():.2f})")
+    # P carries a relative error of ~ln2 * 2^-12 * |scaled score| from the f16 rounding of Q * c: ~1 % at 50, ~20 % at 1300 on the
+    # (few) keys that share the top of a nearly one-hot row
+    close(got, ref, rel=2e-3, abs_frac=4e-3 if gain <= 6 else 4e-2)
 
 
 @pytest.mark.parametrize("b,frames,pixels,heads,d", [(2, 5, 64, 8, 40), (1, 5, 16, 8, 160), (2, 5, 33, 8, 8), (1, 3, 20, 4, 16)])

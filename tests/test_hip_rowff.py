@@ -80,7 +80,7 @@ def test_ff_fused_in_place_and_vs_unfused_path(hiplib):
     bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
     hip.pack_geglu_rows(dev["w1"].data_ptr(), dev["b1"].data_ptr(), 8 * C, C, wp.data_ptr(), bp.data_ptr())
     hid = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
-    wsb = torch.zeros(1 << 24, dtype=torch.uint8, device=DEV)
+    wsb = torch.full((1 << 24,), 0xFF, dtype=torch.uint8, device=DEV)   # NaN-filled workspace
     hip.gemm(hip.GemmDesc(M, 8 * C, C, C, 4 * C, 0, hip.EPI_BIAS | hip.EPI_GEGLU, 1, 0, 1.0, 1), a.data_ptr(), wp.data_ptr(),
              bp.data_ptr(), 0, 0, hid.data_ptr(), wsb.data_ptr(), wsb.numel())
     w2h = dev["w2"].half().contiguous()
@@ -229,7 +229,7 @@ def test_rowchain_groupnorm_prologue(hiplib, frames, rows, samples):
     x16 = x.half().to(DEV)
     gd = hip.GroupNormDesc(samples, rows, C, G, C, C, 1e-6, 0)
     wsb = hip.groupnorm_workspace_bytes(gd)
-    gws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    gws = torch.full((max(wsb, 16),), 0xFF, dtype=torch.uint8, device=DEV)
     gg, gb = gn_g.to(DEV), gn_b.to(DEV)
     # (1) separate launches
     a16 = torch.empty_like(x16)
@@ -292,7 +292,7 @@ def test_rowchain_ff_then_projection(hiplib, M):
     _, ff2, _ = _run_chain(a16, res.half().to(DEV), w, 0, M, 1)
     out2 = torch.empty(M, C, dtype=torch.float16, device=DEV)
     gd = hip.GemmDesc(M, C, C, ff2.stride(0), C, C, 1 | 4, 1, 0, 1.0, 0, 0)
-    wsz = torch.zeros(max(hip.gemm_workspace_bytes(gd), 16), dtype=torch.uint8, device=DEV)
+    wsz = torch.full((max(hip.gemm_workspace_bytes(gd), 16),), 0xFF, dtype=torch.uint8, device=DEV)
     hip.gemm(gd, ff2.data_ptr(), wzd.half().data_ptr(), bzd.data_ptr(), 0, z16.data_ptr(), out2.data_ptr(), wsz.data_ptr(), wsz.numel())
     torch.cuda.synchronize()
     close(out[:M, :C], out2.float().cpu())

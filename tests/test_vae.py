@@ -82,7 +82,7 @@ def test_conv3x3_pad_after_only(n, H, W, cin, cout):
     hip.pack_conv3x3(wd.data_ptr(), cout, cin, cin, wp.data_ptr())
     out = torch.empty(n * (H // 2) * (W // 2), cout, dtype=torch.float16, device="cuda")
     d = hip.ConvDesc(n, H, W, cin, cout, 2, 0, cin, cout, 0, hip.EPI_BIAS, 1, 0, 1.0, 0, 1)
-    wsb = torch.zeros(max(hip.conv3x3_workspace_bytes(d), 256), dtype=torch.uint8, device="cuda")
+    wsb = torch.full((max(hip.conv3x3_workspace_bytes(d), 256),), 0xFF, dtype=torch.uint8, device="cuda")   # NaN-filled
     hip.conv3x3(d, xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), 0, 0, out.data_ptr(), wsb.data_ptr(), wsb.numel())
     torch.cuda.synchronize()
     got = out.float().cpu().reshape(n, H // 2, W // 2, cout).permute(0, 3, 1, 2)

@@ -89,7 +89,7 @@ def bench_gemm(variants, rounds):
             hip.set_igemm_variant(max(v, -1))
             d = hip.GemmDesc(M, N, K, K, nout, nout, epi, 1, 0, 1.0, SPLIT_K)
             wsb = hip.gemm_workspace_bytes(d)
-            ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=DEV)
+            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
             fn = lambda: hip.gemm(d, A.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, res.data_ptr(), out.data_ptr(),
                                   ws.data_ptr(), ws.numel())
             med, mn = timeit(fn, rounds)
@@ -128,7 +128,7 @@ def bench_conv(variants, rounds):
             hip.set_igemm_variant(max(v, -1))
             d = hip.ConvDesc(n, H, W, cin, cout, 1, 0, cin, cout, 0, 1, 1, 0, 1.0, 0)
             wsb = hip.conv3x3_workspace_bytes(d)
-            ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=DEV)
+            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
             fn = lambda: hip.conv3x3(d, x.data_ptr(), w.data_ptr(), bias.data_ptr(), 0, 0, out.data_ptr(), ws.data_ptr(),
                                      ws.numel())
             med, mn = timeit(fn, rounds)
