@@ -88,6 +88,34 @@ typedef struct {
 int rcdm_gemm_ln(const rcdm_gemm_desc* d, const rcdm_ln_fuse* ln, const void* A, const void* W, const float* bias,
                  const void* residual, void* out, void* stream);
 
+/* Deferred LayerNorm: the nn.LayerNorm between two token GEMMs (attention.py:482,502,514: norm1/2/3 in front of to_q|k|v,
+ * attn2.to_q and the GEGLU projection; motion_module.py:236,243: norms[i] + pos_encoder, ff_norm) without a launch of its
+ * own and without the normalised tensor ever existing in HBM.  With W' = W diag(gamma) and b' = b + W beta (folded once, at
+ * pack time; for pos_encoder a per-frame row table b'_f = b' + W pe_f passed as `rowvec`):
+ *     LayerNorm(x) W^T + b  =  rstd (x W'^T) - (rstd mean) S + b',      S[n] = sum_c f16(W'[n][c]).
+ *   PRODUCER (the GEMM that writes the rows x, e.g. to_out + residual or proj_in): stat_out[m][stat_parts] (float2 each)
+ *     = (sum, sum of squares) of the f16 values it stores to row m, one slot per column tile of its launch.  stat_parts
+ *     must equal rcdm_gemm_stat_parts(d) (the column-tile count of the tile shape a statistics-producing launch of this
+ *     shape uses; RCDM_ESHAPE otherwise).  Plain / bias / row-vector / residual epilogues, no GEGLU, no split-K.
+ *   CONSUMER (A = the RAW rows x, W = f16(W'), bias = b', colsum = S in the packed column order of W): stat_in / parts_in
+ *     = the producer's partials of the A rows, C = the LayerNorm width (= K), eps.  Its epilogue forms (rstd, mean rstd)
+ *     per row from the partials (var = E[x^2] - mean^2 in fp32) and applies the identity before bias / row vector /
+ *     GELU / GEGLU / residual.  Every epilogue form, no split-K; parts_in <= 20.
+ *   One call may be both.  Both sides NULL = rcdm_gemm. */
+typedef struct {
+  float* stat_out;            /* producer: [M (+ dup rows)][stat_parts][2] fp32, or NULL */
+  int32_t stat_parts;
+  const float* stat_in;       /* consumer: [M][parts_in][2] fp32, or NULL */
+  int32_t parts_in;
+  const float* colsum;        /* consumer: S [N] fp32 (16-byte aligned) */
+  float eps;                  /* LayerNorm eps (1e-5) */
+  int32_t C;                  /* LayerNorm width = K of the consumer */
+} rcdm_lnx;
+int rcdm_gemm_stat_parts(const rcdm_gemm_desc* d);   /* 0: a statistics-producing launch of this shape is not available */
+int rcdm_gemm_lnx(const rcdm_gemm_desc* d, const rcdm_lnx* x, const void* A, const void* W, const float* bias,
+                  const float* rowvec, const void* residual, void* out, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
 /* tuning/test knob for rcdm_gemm and rcdm_conv3x3: -1 = automatic (default: chosen per shape; env
  * RCDM_IGEMM=dma128|dma256|dma64 overrides), tile (pixels x channels): 1 = 128x128, 2 = 256x256, 3 = 64x64,
  * 4 = 64x64 with a four-slot LDS ring, 5 = 128x64.

@@ -94,6 +94,41 @@ __device__ __forceinline__ uint4 geglu8(uint4 h, uint4 g, const float (&bh)[8], 
   return o.u;
 }
 
+// fma(f16 half `sel` of the dword h, s, c) in fp32: v_fma_mix_f32 converts the f16 source on the fly
+__device__ __forceinline__ float mix_f16_f32(unsigned h, int sel, float s, float c) {
+  float t;
+  if (sel) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(h), "v"(s), "v"(c));
+  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(t) : "v"(h), "v"(s), "v"(c));
+  return t;
+}
+// {f16(fma(r.lo, s, t0)), f16(fma(r.hi, s, t1))}: fp32 fma of the f16 halves of r, one rounding each, packed
+__device__ __forceinline__ unsigned mix_f16_pack(unsigned r, float s, float t0, float t1) {
+  unsigned o;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(o) : "v"(r), "v"(s), "v"(t0), "v"(t1));
+  return o;
+}
+
+// GEGLU behind a deferred LayerNorm (rcdm_gemm_lnx): the staged halfs are x W'^T of the RAW rows; (h * rstd - mr * S + b)
+__device__ __forceinline__ uint4 geglu8_lnx(uint4 h, uint4 g, const float (&bh)[8], const float (&bg)[8], const float (&sh)[8],
+                                            const float (&sg)[8], float rstd, float mr, float sc) {
+  union P { uint4 u; unsigned w[4]; f16 e[8]; } hh, gg, o;
+  hh.u = h;
+  gg.u = g;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2 hb = __builtin_elementwise_fma(splat2(-mr), f32x2{sh[2 * k], sh[2 * k + 1]}, f32x2{bh[2 * k], bh[2 * k + 1]});
+    const f32x2 gb = __builtin_elementwise_fma(splat2(-mr), f32x2{sg[2 * k], sg[2 * k + 1]}, f32x2{bg[2 * k], bg[2 * k + 1]});
+    // v_fma_mix_f32 converts the staged half on the fly: no separate v_cvt per element
+    const f32x2 hv = {mix_f16_f32(hh.w[k], 0, rstd, hb.x), mix_f16_f32(hh.w[k], 1, rstd, hb.y)};
+    const f32x2 gv = {mix_f16_f32(gg.w[k], 0, rstd, gb.x), mix_f16_f32(gg.w[k], 1, rstd, gb.y)};
+    const f32x2 r = hv * gelu2(gv) * splat2(sc);
+    o.e[2 * k] = (f16)r.x;
+    o.e[2 * k + 1] = (f16)r.y;
+  }
+  return o.u;
+}
+
 // sum over groups of LPR consecutive lanes (LPR a power of two, 8..64), result in every lane of the group: DPP steps
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: no LDS crossbar), ds_bpermute only across 16-lane rows
 template <int CTRL>
@@ -109,6 +144,63 @@ __device__ __forceinline__ float group_sum(float v) {
   if constexpr (LPR >= 32) v += __shfl_xor(v, 16, 64);
   if constexpr (LPR >= 64) v += __shfl_xor(v, 32, 64);
   return v;
+}
+
+// Deferred LayerNorm, consumer side: TPR consecutive lanes (1, 2 or 4) share a row and split its <= MAXP partial
+// (sum, sum of squares) slots; finish() gives (rstd, mean * rstd) of the row in every lane of the group.
+template <int TPR, int MAXP>
+struct LnxRow {
+  static constexpr int NL = (MAXP + TPR - 1) / TPR;
+  f32x2 v[NL];
+  // every load is issued unconditionally at a clamped index and zeroed by a select afterwards: a load under a
+  // per-element runtime condition makes hipcc branch around each one and wait for it (NL dependent L2 round trips)
+  __device__ __forceinline__ void load(const float* stat, int m, bool live, int parts, int sub) {
+    const f32x2* row = (const f32x2*)stat + (size_t)(live ? m : 0) * parts;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int idx = sub + j * TPR;
+      v[j] = row[min(idx, parts - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const bool ok = live && sub + j * TPR < parts;
+      v[j].x = ok ? v[j].x : 0.f;
+      v[j].y = ok ? v[j].y : 0.f;
+    }
+  }
+  __device__ __forceinline__ void finish(float invC, float eps, float& rstd, float& mr) const {
+    f32x2 s = v[0];
+#pragma unroll
+    for (int j = 1; j < NL; ++j) s += v[j];
+    if constexpr (TPR >= 2) {
+      s.x += dpp_f32<0xB1>(s.x);
+      s.y += dpp_f32<0xB1>(s.y);
+    }
+    if constexpr (TPR >= 4) {
+      s.x += dpp_f32<0x4E>(s.x);
+      s.y += dpp_f32<0x4E>(s.y);
+    }
+    const float mean = s.x * invC;
+    float var = __builtin_fmaf(-mean, mean, s.y * invC);
+    if (var < 0.f) var = 0.f;
+    rstd = rsqrtf(var + eps);
+    mr = mean * rstd;
+  }
+};
+// (rstd, mean rstd) of row m with the load count sized to the slot count: <= 8 slots (C <= 1024 behind 128-wide producer
+// tiles) take the short form
+template <int TPR, int MAXP>
+__device__ __forceinline__ void lnx_row(const float* stat, int m, bool live, int parts, int sub, float invC, float eps,
+                                        float& rstd, float& mr) {
+  if (parts <= 8) {   // wave-uniform
+    LnxRow<TPR, 8> r;
+    r.load(stat, m, live, parts, sub);
+    r.finish(invC, eps, rstd, mr);
+  } else {
+    LnxRow<TPR, MAXP> r;
+    r.load(stat, m, live, parts, sub);
+    r.finish(invC, eps, rstd, mr);
+  }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -28,6 +28,9 @@
 #include <string.h>
 #include "common.h"
 #include "igemm_args.h"
+#ifndef RCDM_LNX_ABLATE
+#define RCDM_LNX_ABLATE 0   // debug builds (tools/lnx_bench.py): 1 = no partial-statistics loads, 2 = no S / bias vectors in the items
+#endif
 
 namespace {
 
@@ -82,21 +85,6 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n,
   if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + oc + p.dup) = o.u;
 }
 
-// fma(f16 half `sel` of the dword h, s, c) in fp32: v_fma_mix_f32 converts the f16 source on the fly
-__device__ __forceinline__ float mix_f16_f32(unsigned h, int sel, float s, float c) {
-  float t;
-  if (sel) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(h), "v"(s), "v"(c));
-  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(t) : "v"(h), "v"(s), "v"(c));
-  return t;
-}
-// {f16(fma(r.lo, s, t0)), f16(fma(r.hi, s, t1))}: fp32 fma of the f16 halves of r, one rounding each, packed
-__device__ __forceinline__ unsigned mix_f16_pack(unsigned r, float s, float t0, float t1) {
-  unsigned o;
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "=&v"(o) : "v"(r), "v"(s), "v"(t0), "v"(t1));
-  return o;
-}
-
 // Every load the block has in flight — the next tile's first DMA pieces (issued a k-step and a staging phase ago) and
 // this tile's residual / bias prefetches — is waited for right before the tile's first output store, with the
 // compiler-visible form of s_waitcnt: (a) once stores are in flight vmcnt cannot separate them from DMA pieces, so this
@@ -122,8 +110,10 @@ constexpr int TRACE_SLOTS = 8;
 constexpr int TRACE_SLOTS = 4;
 #endif
 
-template <int TAPS, int BM_, int BN_, int WM, int WN, int NSTAGE, bool E16>
-__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmArgs p) {
+template <int TAPS, int BM_, int BN_, int WM, int WN, int NSTAGE, bool E16, int LX = 0>  // LX: deferred-LayerNorm epilogues (rcdm_gemm_lnx) compiled in: 1 = row statistics only, 2 = consumer (+ statistics)
+// (second launch bound = waves per SIMD the tile's LDS footprint allows: 4 blocks of 64x64, 3 of 128x64, 2 of 128x128 per CU)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM_ * BN_ <= 64 * 64 && NSTAGE == 2) ? 4 : (WM * WN == 4 && BM_ * BN_ <= 128 * 64) ? 3 : 2)
+void igemm_dma_kernel(const IgemmArgs p) {
   constexpr int NW = WM * WN;             // waves
   constexpr int FM = BM_ / WM / 32;       // pixel fragments per wave
   constexpr int FN = BN_ / WN / 32;       // channel fragments per wave
@@ -135,6 +125,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // deferred LayerNorm, consumer side (LX & 2): LTPR threads per tile row sum the row's partial statistics at the tile's
+  // FIRST k-step — the loads go out in front of the wait for that step's operands and cost no round trip of their own —
+  // and (rstd, mean rstd) sits in a [BM][2] table behind the ring until the epilogue reads it
+  constexpr bool LXC = (LX & 2) != 0;
+  constexpr int LTPR = (WM * WN * 64) / BM_;
+  static_assert(!LXC || LTPR == 1 || LTPR == 2 || LTPR == 4, "threads per row of the LayerNorm table");
+  float* ltab = (float*)(smem + NSTAGE * (BM_ + BN_) * 128);
+  const bool lnx_k = LXC && p.lnx_stat != nullptr;
 
   const int ntiles = p.tilesM * p.tilesN;
   const int G = gridDim.x;
@@ -290,6 +288,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     // younger steps may still be in flight); the barrier makes everybody's visible and also guarantees every
     // wave is done reading the slot of step g-1, which the issue below refills
     const int younger = min(NSTAGE - 2, total - 1 - g);
+    LnxRow<LTPR, LXC ? kLnxMaxParts : 1> lrow;
+    const bool lx_now = lnx_k && c_ks == 0;
+    if constexpr (LXC) if (lx_now) {
+      const int lm = cm0 + t / LTPR;
+      lrow.load(p.lnx_stat, lm, lm < p.M, p.lnx_parts, t % LTPR);
+    }
     if (post_epi == 2) {
       // first step of a new tile: every DMA piece issued so far was waited for inside the epilogue, BEFORE its output
       // stores were issued — nothing to wait for here, and the stores' round trip to L2 (vmcnt counts them, and they
@@ -306,6 +310,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
       post_epi = 0;
     }
     __builtin_amdgcn_s_barrier();
+    if constexpr (LXC) if (lx_now) {   // (after the barrier: the previous tile's epilogue is done reading the table)
+      float rs_ = 1.f, mr_ = 0.f;
+#if !(RCDM_LNX_ABLATE & 1)
+      lrow.finish(p.lnx_invC, p.lnx_eps, rs_, mr_);
+#endif
+      if (t % LTPR == 0) *(f32x2*)(ltab + 2 * (t / LTPR)) = f32x2{rs_, mr_};
+    }
     // 8-wave blocks put two waves on every SIMD, released by the same barrier: if both issued their DMA pieces first
     // (each piece stalls the issuing wave for ~100 cycles) the SIMD's matrix pipe would idle through both bursts.
     // The second half of the block therefore issues after its first two k-chunks, under the first half's MFMAs.
@@ -382,6 +393,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
         load8(p.rowvec + (size_t)smp0 * p.ldt + pn, rvA);
         if (m_switch < p.M && m_switch < cm0 + BM_) load8(p.rowvec + (size_t)(smp0 + 1) * p.ldt + pn, rvB);
       }
+      // deferred LayerNorm of the A rows (rcdm_gemm_lnx): LTPR threads per tile row sum that row's partial statistics;
+      // (rstd, mean rstd) go to a [BM][2] table behind the ring, published by the staging barrier of the first pass
+      const bool lnx = LXC && p.lnx_stat != nullptr;
+      const bool stat_on = LX != 0 && p.stat_out != nullptr;
+      float sA[LXC ? 8 : 1], sB[LXC ? 8 : 1];
+#pragma unroll
+      for (int e = 0; e < (LXC ? 8 : 1); ++e) sA[e] = sB[e] = 0.f;
+      if constexpr (LXC) if (lnx && pn_ok) {
+        load8(p.lnx_S + pn, sA);
+        if (geglu) load8(p.lnx_S + pn + kGegluGroup, sB);
+      }
+      const int stat_tn = cn0 / BN_;
+      const int dup_rows = p.dup ? (int)(p.dup / p.ldc) : 0;
       if (WHOLE && !geglu) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps)
@@ -449,7 +473,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
                 const int m = mbase + gr0 + (it0 + k) * G_RPI;
                 if (m < p.M && pn_ok) {
                   Pack16 o;
-                  o.u = geglu8(hh[k].u, gg[k].u, bA, bB, sc);
+                  if constexpr (LXC) {
+                    if (lnx) {
+                      const f32x2 rs = *(const f32x2*)(ltab + 2 * (m - cm0));
+                      o.u = geglu8_lnx(hh[k].u, gg[k].u, bA, bB, sA, sB, rs.x, rs.y, sc);
+                    } else {
+                      o.u = geglu8(hh[k].u, gg[k].u, bA, bB, sc);
+                    }
+                  } else {
+                    o.u = geglu8(hh[k].u, gg[k].u, bA, bB, sc);
+                  }
                   *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
                   if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + oc + p.dup) = o.u;
                 }
@@ -477,16 +510,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
               if (it0 + k < P_ITEMS) {
                 const int it = it0 + k;
                 const int m = mbase + pr0 + it * P_RPI;
+                float st1 = 0.f, st2 = 0.f;   // producer side of a deferred LayerNorm: sums over this thread's 8 outputs
                 if (m < p.M && pn_ok) {
                   const Pack16& rr = resv[WHOLE ? ps : 0][it];
                   Pack16 o;
                   if (gelu_on || (has_rv && !rv_pair)) {
-                    // rare forms (stage-1 GELU feed-forward; row vector with fewer rows per sample than the tile):
-                    // plain fp32 arithmetic, row vector read in place
+                    // rare forms (stage-1 GELU feed-forward; row vector with fewer rows per sample than the tile) and the
+                    // deferred LayerNorm of the A rows: plain fp32 arithmetic
                     float v[8];
+                    if (LXC && lnx) {
+                      const f32x2 rs = *(const f32x2*)(ltab + 2 * (m - cm0));
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (float)hh[k].e[e] + bA[e];
-                    if (has_rv) {
+                      for (int e = 0; e < 8; ++e)
+                        v[e] = __builtin_fmaf((float)hh[k].e[e], rs.x, __builtin_fmaf(-rs.y, sA[LXC ? e : 0], bA[e]));
+                    } else {
+#pragma unroll
+                      for (int e = 0; e < 8; ++e) v[e] = (float)hh[k].e[e] + bA[e];
+                    }
+                    if (has_rv && rv_pair) {
+                      const bool second = m >= m_switch;
+#pragma unroll
+                      for (int e = 0; e < 8; ++e) v[e] += second ? rvB[e] : rvA[e];
+                    } else if (has_rv) {
                       float rv[8];
                       load8(p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + pn, rv);
 #pragma unroll
@@ -499,16 +544,43 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
                     for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + (float)rr.e[e]) * sc);
                   } else {
                     const bool second = m >= m_switch;
+                    // deferred LayerNorm: h * (rstd sc) + ((bias + row vector) sc - (mean rstd sc) S), same two-instruction form
+                    float s_eff = sc, nmr = 0.f;
+                    if (LXC && lnx) {
+                      const f32x2 rs = *(const f32x2*)(ltab + 2 * (m - cm0));
+                      s_eff = rs.x * sc;
+                      nmr = -rs.y * sc;
+                    }
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                      const float c0 = second ? cB[2 * d] : cA[2 * d], c1 = second ? cB[2 * d + 1] : cA[2 * d + 1];
-                      const float t0 = mix_f16_f32(hh[k].v[d], 0, sc, c0);
-                      const float t1 = mix_f16_f32(hh[k].v[d], 1, sc, c1);
+                      float c0 = second ? cB[2 * d] : cA[2 * d], c1 = second ? cB[2 * d + 1] : cA[2 * d + 1];
+                      if (LXC && lnx && !(RCDM_LNX_ABLATE & 2)) {
+                        c0 = __builtin_fmaf(nmr, sA[LXC ? 2 * d : 0], c0);
+                        c1 = __builtin_fmaf(nmr, sA[LXC ? 2 * d + 1 : 0], c1);
+                      }
+                      const float t0 = mix_f16_f32(hh[k].v[d], 0, s_eff, c0);
+                      const float t1 = mix_f16_f32(hh[k].v[d], 1, s_eff, c1);
                       o.v[d] = mix_f16_pack(rr.v[d], sc, t0, t1);
                     }
                   }
                   *(uint4*)(p.out + (size_t)m * p.ldc + pn) = o.u;
                   if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + pn + p.dup) = o.u;
+                  if (stat_on) {   // (v_dot2c_f32_f16 was tried for two elements per instruction: wrong sums on gfx950)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                      const float f = (float)o.e[e];
+                      st1 += f;
+                      st2 = __builtin_fmaf(f, f, st2);
+                    }
+                  }
+                }
+                if (stat_on) {   // wave-uniform; every lane of the P_TPR-lane row group takes part in the DPP sums
+                  st1 = group_sum<P_TPR>(st1);
+                  st2 = group_sum<P_TPR>(st2);
+                  if (pc8 == 0 && m < p.M) {
+                    *(f32x2*)(p.stat_out + ((size_t)m * p.stat_parts + stat_tn) * 2) = f32x2{st1, st2};
+                    if (dup_rows) *(f32x2*)(p.stat_out + ((size_t)(m + dup_rows) * p.stat_parts + stat_tn) * 2) = f32x2{st1, st2};
+                  }
                 }
               }
           }
@@ -712,7 +784,8 @@ bool pick_16(const IgemmArgs& a) {
   if (taps == 1) {
     // plain projections (no epilogue work: the staged halfs are copied out) that split into whole rounds of 160x160 tiles:
     // the cross-attention queries of the 32x32 level and of the shared-prefix half batch (tools/autotune.py: 17.3 -> 13.8 us)
-    if (a.epi == 0 && a.out_scale == 1.0f && a.M % 160 == 0 && a.N % 160 == 0 && (a.M / 160) * (a.N / 160) >= 256 &&
+    const bool plain = a.epi == 0 || (a.lnx_stat && !(a.epi & (RCDM_EPI_RESIDUAL | RCDM_EPI_GELU | RCDM_EPI_GEGLU)));
+    if (plain && a.out_scale == 1.0f && a.M % 160 == 0 && a.N % 160 == 0 && (a.M / 160) * (a.N / 160) >= 256 &&
         a.Cin <= 640 && a.N <= 640)
       return true;
     return a.N >= 960 && a.N >= 3 * a.Cin && a.M >= 2048 && a.Cin <= 1280;  // wide N only: qkv (3C), GEGLU (8C)
@@ -733,7 +806,7 @@ int pick_variant(const IgemmArgs& a) {
     const char* e = getenv("RCDM_PP");
     g_pp_mode = e ? atoi(e) : 1;
   }
-  if (g_pp_mode) {
+  if (g_pp_mode && !a.stat_out) {   // row statistics come out of the igemm_dma epilogue only
     if (pick_16(a)) return kVar16;
     const int pp = pick_pp(a);
     if (pp >= 0) return kFirstPP + pp;
@@ -823,11 +896,12 @@ void set_lds(K kernel, int bytes) {
 
 template <int TAPS>
 int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  constexpr int LDS_128 = 2 * (128 + 128) * 128;   // 64 KB  (two blocks per CU)
-  constexpr int LDS_256 = 2 * (256 + 256) * 128;   // 128 KB
-  constexpr int LDS_64 = 2 * (64 + 64) * 128;      // 32 KB
-  constexpr int LDS_64D = 4 * (64 + 64) * 128;     // 64 KB  (three steps in flight)
-  constexpr int LDS_128x64 = 2 * (128 + 64) * 128; // 48 KB
+  constexpr int LTAB = 2048;                       // [BM][2] floats behind the ring: the deferred-LayerNorm row table
+  constexpr int LDS_128 = 2 * (128 + 128) * 128 + LTAB;   // 64 KB  (two blocks per CU)
+  constexpr int LDS_256 = 2 * (256 + 256) * 128 + LTAB;   // 128 KB
+  constexpr int LDS_64 = 2 * (64 + 64) * 128 + LTAB;      // 32 KB  (four blocks per CU)
+  constexpr int LDS_64D = 4 * (64 + 64) * 128 + LTAB;     // 64 KB  (three steps in flight)
+  constexpr int LDS_128x64 = 2 * (128 + 64) * 128 + LTAB; // 48 KB  (three blocks per CU)
   static bool attr_set[64] = {};
   if (rcdm_first_on_device(attr_set)) {
     set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, false>, LDS_128);
@@ -840,6 +914,18 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
     set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2, true>, LDS_64);
     set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4, true>, LDS_64D);
     set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2, true>, LDS_128x64);
+    if constexpr (TAPS == 1) {
+      set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, true, 1>, LDS_128);
+      set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2, true, 1>, LDS_256);
+      set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2, true, 1>, LDS_64);
+      set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4, true, 1>, LDS_64D);
+      set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2, true, 1>, LDS_128x64);
+      set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, true, 2>, LDS_128);
+      set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2, true, 2>, LDS_256);
+      set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2, true, 2>, LDS_64);
+      set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4, true, 2>, LDS_64D);
+      set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2, true, 2>, LDS_128x64);
+    }
   }
   if (a.splits > 1) {
     const size_t need = (size_t)a.splits * a.M * a.N * sizeof(float);
@@ -850,6 +936,10 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   }
   a.trace = g_trace;
   a.dbg = 0;
+  if (a.stat_out && (variant >= kFirstPP || a.splits > 1 || (a.epi & RCDM_EPI_GEGLU) || a.stat_parts != a.tilesN))
+    return RCDM_ESHAPE;
+  if ((a.stat_out || a.lnx_stat) && TAPS != 1) return RCDM_ESHAPE;
+  if (a.lnx_stat && (a.splits > 1 || !a.lnx_S || a.lnx_parts < 1 || a.lnx_parts > kLnxMaxParts)) return RCDM_ESHAPE;
   if (variant == kVar16) {
     int rc = rcdm_igemm16_launch(a, TAPS, stream);
     if (rc) return rc;
@@ -898,8 +988,19 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   dim3 grid(gx, a.splits);
   // E16 = true: direct launch with the fused epilogue (f16 staging); false: split-K slab writer (fp32 staging)
   const bool e16 = a.splits == 1;
+  const bool lx = a.stat_out || a.lnx_stat;   // (TAPS == 1 and e16 only: checked above)
 #define RCDM_IGEMM_LAUNCH(BM, BN, WM, WN, NS, THREADS, LDS)                                                           \
   do {                                                                                                                \
+    if constexpr (TAPS == 1) {                                                                                        \
+      if (a.lnx_stat) {                                                                                               \
+        hipLaunchKernelGGL((igemm_dma_kernel<TAPS, BM, BN, WM, WN, NS, true, 2>), grid, dim3(THREADS), LDS, stream, a); \
+        break;                                                                                                        \
+      }                                                                                                               \
+      if (lx) {                                                                                                       \
+        hipLaunchKernelGGL((igemm_dma_kernel<TAPS, BM, BN, WM, WN, NS, true, 1>), grid, dim3(THREADS), LDS, stream, a); \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
     if (e16) hipLaunchKernelGGL((igemm_dma_kernel<TAPS, BM, BN, WM, WN, NS, true>), grid, dim3(THREADS), LDS, stream, a); \
     else hipLaunchKernelGGL((igemm_dma_kernel<TAPS, BM, BN, WM, WN, NS, false>), grid, dim3(THREADS), LDS, stream, a);    \
   } while (0)
@@ -989,6 +1090,41 @@ int rcdm_gemm(const rcdm_gemm_desc* d, const void* A, const void* W, const float
   a.res = (const f16*)residual; a.out = (f16*)out;
   int rc = check_common(a);
   if (rc) return rc;
+  int variant = 0;
+  fill_common(a, d->split_k, &variant);
+  return launch<1>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int rcdm_gemm_stat_parts(const rcdm_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  IgemmArgs a{};
+  from_gemm(d, a);
+  a.stat_out = (float*)16;   // any non-null value: the tile choice of a statistics-producing launch
+  fill_common(a, d->split_k);
+  return a.splits > 1 ? 0 : a.tilesN;
+}
+
+int rcdm_gemm_lnx(const rcdm_gemm_desc* d, const rcdm_lnx* x, const void* A, const void* W, const float* bias,
+                  const float* rowvec, const void* residual, void* out, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+  if (!d || !x) return RCDM_EINVAL;
+  IgemmArgs a{};
+  from_gemm(d, a);
+  a.A = (const f16*)A; a.W = (const f16*)W; a.bias = bias; a.rowvec = rowvec;
+  a.res = (const f16*)residual; a.out = (f16*)out;
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (x->stat_out) {
+    if (x->stat_parts <= 0 || ((uintptr_t)x->stat_out & 7)) return RCDM_EINVAL;
+    a.stat_out = x->stat_out;
+    a.stat_parts = x->stat_parts;
+  }
+  if (x->stat_in) {
+    if (!x->colsum || x->parts_in <= 0 || x->C <= 0 || ((uintptr_t)x->stat_in & 7) || ((uintptr_t)x->colsum & 15)) return RCDM_EINVAL;
+    if (x->parts_in > kLnxMaxParts) return RCDM_ESHAPE;
+    a.lnx_stat = x->stat_in; a.lnx_S = x->colsum; a.lnx_parts = x->parts_in;
+    a.lnx_invC = 1.0f / (float)x->C; a.lnx_eps = x->eps;
+  }
   int variant = 0;
   fill_common(a, d->split_k, &variant);
   return launch<1>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);

@@ -134,6 +134,15 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   issue(0, 0);
+  // deferred LayerNorm of the A rows (rcdm_gemm_lnx): thread t < BM sums row t's partial statistics now — the loads ride
+  // on the wait for the first operand stage — and carries (rstd, mean rstd) in two registers to the epilogue
+  f32x2 lx_pre = {1.f, 0.f};
+  const bool lx_on = TAPS == 1 && !SLAB && p.lnx_stat != nullptr;
+  if (lx_on && t < BM) {
+    float r_ = 1.f, m_ = 0.f;
+    lnx_row<1, kLnxMaxParts>(p.lnx_stat, cm0 + t, cm0 + t < p.M, p.lnx_parts, 0, p.lnx_invC, p.lnx_eps, r_, m_);
+    lx_pre = f32x2{r_, m_};
+  }
   for (int g = 0; g < nkl; ++g) {
     // this wave's pieces of step g have landed (nothing newer is in flight); the barrier makes everybody's visible and
     // says everybody is done reading the stage of step g-1, which the issue below refills
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
     if (s == 1.2345678e33f) p.out[0] = (f16)s;
   }
 #else
-  tile_epilogue<FM, FN, SLAB, 256, BM, BN>(p, smem, acc, cm0, cn0, wm * (BM / 2), wn * (BN / 2), l15, kg, t);
+  tile_epilogue<FM, FN, SLAB, 256, BM, BN, false, TAPS == 1>(p, smem, acc, cm0, cn0, wm * (BM / 2), wn * (BN / 2), l15, kg, t, lx_pre, lx_on);
 #endif
 }
 

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
   }
   // every wave is past the last tick: no LDS read and no DMA is outstanding anywhere in the block
 
-  tile_epilogue<FMW, FNW, SLAB, 512, BM, BN, TAPS == 1>(p, smem, acc, cm0, cn0, grp * HM, wn * (BN / 4), l15, kg, t);
+  tile_epilogue<FMW, FNW, SLAB, 512, BM, BN, TAPS == 1, TAPS == 1>(p, smem, acc, cm0, cn0, grp * HM, wn * (BN / 4), l15, kg, t);
 }
 
 template <int FMW, int FNW>

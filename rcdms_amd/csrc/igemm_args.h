@@ -34,7 +34,19 @@ struct IgemmArgs {
   f16* ln_out;
   int ln_ld, ln_rpf, ln_frames;
   float ln_eps;
+  // deferred LayerNorm (rcdm_gemm_lnx).  Producer side: stat_out[m][stat_parts] = (sum, sum of squares) of the f16 values
+  // this launch stores to row m, one slot per column tile (stat_parts == tilesN).  Consumer side: the A rows are the RAW
+  // input x of a LayerNorm whose gamma is folded into W and whose beta into the bias, so LayerNorm(x) W^T =
+  // rstd (x W'^T) - rstd mean S, S[n] = sum_c W'[n][c]: lnx_stat holds the producer's partials of the A rows, the epilogue
+  // forms (rstd, mean rstd) per row and applies them before bias / row vector / GEGLU / residual.
+  float* stat_out;
+  int stat_parts;
+  const float* lnx_stat;
+  const float* lnx_S;
+  int lnx_parts;
+  float lnx_invC, lnx_eps;
 };
+constexpr int kLnxMaxParts = 20;   // partial slots per row a consumer can sum (N = 1280 behind 64-wide producer tiles)
 constexpr int kEpiLN = 1 << 20;  // internal epilogue bit (not part of the C-ABI flags)
 
 // GEGLU packing (rcdm_pack_geglu_rows): packed rows/columns come in groups of 32 = 16 "hidden" + their 16 "gate"

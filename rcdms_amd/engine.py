@@ -118,8 +118,11 @@ if _DROP:
 # single-kernel emitters
 
 def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geglu=False, scale=1.0, split_k=0,
-              gelu=False, dup_rows=0):
-    """out[M][N or N/2] = epi(A[M][K] W[N][K]^T); rowvec = (tensor, elem_offset, ldt, rows_per_sample)."""
+              gelu=False, dup_rows=0, stat=False, lnx=None):
+    """out[M][N or N/2] = epi(A[M][K] W[N][K]^T); rowvec = (tensor, elem_offset, ldt, rows_per_sample).
+    Deferred LayerNorm (rcdm_gemm_lnx): stat=True — also write the row statistics of the stored rows and RETURN their handle
+    (None when this shape has no statistics-producing launch: the caller then emits the stand-alone LayerNorm);
+    lnx=(handle, S) — A holds the RAW rows whose LayerNorm this GEMM consumes, Wt / bias carry gamma / beta (Packer.lnx_*)."""
     epi = 0
     if bias is not None:
         epi |= hip.EPI_BIAS
@@ -137,20 +140,44 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
     ws = plan.scratch("splitk_ws", max(wsb, 256))
     bptr = bias.data_ptr() if bias is not None else 0
     rv_t, rv_off = (rowvec[0], rowvec[1]) if rowvec else (None, 0)
+    handle, x = None, None
+    if stat and LNX and not wsb and not geglu:
+        parts = hip.gemm_stat_parts(d)
+        if 0 < parts <= LNX_MAX_PARTS:
+            handle = _NS(buf=plan.scratch("rowstat", (A.M + dup_rows) * parts * 8), parts=parts, M=A.M, C=N)
+    if lnx is not None:
+        assert not wsb, "deferred LayerNorm consumer cannot be a split-K launch (gemm_lnx_ok)"
+        assert lnx[0].C == K and lnx[0].M >= A.M
+    if handle is not None or lnx is not None:
+        x = hip.Lnx(0, handle.parts if handle else 0, 0, lnx[0].parts if lnx else 0, lnx[1].data_ptr() if lnx else 0, 1e-5, K)
 
     def op():
-        hip.gemm(d, A.ptr, Wt.data_ptr(), bptr, (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0,
-                 residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
+        rvp = (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0
+        if x is not None:
+            x.stat_out = handle.buf.ptr if handle is not None else 0
+            x.stat_in = lnx[0].buf.ptr if lnx is not None else 0
+            hip.gemm_lnx(d, x, A.ptr, Wt.data_ptr(), bptr, rvp, residual.ptr if residual is not None else 0, out.ptr,
+                         ws.ptr, ws.nbytes)
+            return
+        hip.gemm(d, A.ptr, Wt.data_ptr(), bptr, rvp, residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
     n_before = len(plan.ops)
-    plan.add(op, f"gemm M={A.M} N={N} K={K} epi={epi}")
-    plan.keep += [Wt, bias, rv_t]
+    plan.add(op, f"gemm M={A.M} N={N} K={K} epi={epi}" + (" lnx" if lnx is not None else "") + (" stat" if handle is not None else ""))
+    plan.keep += [Wt, bias, rv_t, x, lnx[1] if lnx else None]
     plan.n_launch += 2 if wsb else 1
     # a LayerNorm of exactly these output rows emitted NEXT can ride in this GEMM's epilogue (emit_layernorm)
     plan.last_gemm = None
     if len(plan.ops) == n_before:   # the op was left out (RCDM_DROP_OPS): nothing for a following LayerNorm to replace
-        return
-    if (LN_FUSE and N <= LN_FUSE_MAX_N and A.M >= LN_FUSE_MIN_M and not (geglu or gelu or rowvec) and split_k <= 1 and not wsb):
+        return None
+    if (LN_FUSE and N <= LN_FUSE_MAX_N and A.M >= LN_FUSE_MIN_M and not (geglu or gelu or rowvec) and split_k <= 1 and not wsb
+            and handle is None and lnx is None):
         plan.last_gemm = dict(n_ops=len(plan.ops), d=d, A=A, Wt=Wt, bptr=bptr, residual=residual, out=out, N=N, K=K, epi=epi)
+    return handle
+
+
+def gemm_lnx_ok(M, N, K, lda, ldc, geglu=False, dup_rows=0):
+    """Whether a deferred-LayerNorm consumer GEMM of this shape is a single launch (no split-K slabs)."""
+    d = hip.GemmDesc(M, N, K, lda, ldc, 0, hip.EPI_GEGLU if geglu else 0, 1, 0, 1.0, 0, dup_rows)
+    return hip.gemm_workspace_bytes(d) == 0
 
 
 def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=None, rowvec=None, residual=None,
@@ -245,6 +272,11 @@ def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out):
 # do not overlap, against 21-23 us + 11-13 us for the two well-overlapped launches it replaces.
 LN_FUSE = os.environ.get("RCDM_LN_FUSE", "0") != "0"
 LN_FUSE_MAX_N, LN_FUSE_MIN_M = 320, 20480
+# Deferred LayerNorm (rcdm_gemm_lnx) wherever the row-stationary chains are not used (the 32x32 / 16x16 / 8x8 levels): the
+# GEMM in front of a LayerNorm emits row statistics, the GEMM behind it takes the raw rows with gamma / beta folded into its
+# weights — no LayerNorm launch, no normalised tensor in HBM.  RCDM_LNX=0 keeps the stand-alone launches (same-process A/B).
+LNX = os.environ.get("RCDM_LNX", "1") != "0"
+LNX_MAX_PARTS = 20
 XATTN_MAX_KEYS = 96   # rcdm_xattn: cross-attention with all scores of a query in registers
 
 
@@ -336,6 +368,41 @@ class Packer:
         hip.pack_geglu_rows(w.data_ptr(), b.data_ptr(), n_out, K, wd.data_ptr(), bd.data_ptr())
         self._tmp += [w, b]
         return wd, bd
+
+    def lnx_mat(self, keys, gamma, beta, bias=None, pe=None):
+        """A LayerNorm folded into the stacked [n_i][K] matrices behind it (rcdm_gemm_lnx consumer operands):
+        W = f16(W diag(gamma)), S[n] = sum_c W[n][c] (of the ROUNDED matrix: what the MFMA sums), b = bias + W beta;
+        pe [F][K] (motion modules): tab[f] = b + W pe_f, the per-frame row table."""
+        if not LNX:
+            return None
+        w = torch.cat([self.f32(k).reshape(self.sd[k].shape[0], -1) for k in keys], dim=0).contiguous()
+        wg = (w * gamma[None, :]).contiguous()
+        dst = torch.empty(wg.shape, dtype=torch.float16, device=self.device)
+        hip.pack_f16(wg.data_ptr(), dst.data_ptr(), wg.numel())   # (torch's current stream: ordered with the torch ops around it)
+        S = dst.float().sum(dim=1).contiguous()
+        b = (w * beta[None, :]).sum(dim=1)
+        if bias is not None:
+            b = b + bias
+        tab = None
+        if pe is not None:
+            tab = torch.stack([b + (w * pe[f][None, :]).sum(dim=1) for f in range(pe.shape[0])]).contiguous()
+        self._tmp += [w, wg]
+        return _NS(W=dst, S=S, b=b.contiguous(), tab=tab)
+
+    def lnx_geglu(self, wkey, bkey, gamma, beta):
+        """The same for the GEGLU projection: folded, then packed like Packer.geglu (16 | 16 row interleave)."""
+        if not LNX:
+            return None
+        w, b = self.f32(wkey), self.f32(bkey)
+        n_out, K = w.shape
+        wg = (w * gamma[None, :]).contiguous()
+        bb = (b + (w * beta[None, :]).sum(dim=1)).contiguous()
+        wd = torch.empty(n_out, K, dtype=torch.float16, device=self.device)
+        bd = torch.empty(n_out, dtype=torch.float32, device=self.device)
+        hip.pack_geglu_rows(wg.data_ptr(), bb.data_ptr(), n_out, K, wd.data_ptr(), bd.data_ptr())
+        S = wd.float().sum(dim=1).contiguous()
+        self._tmp += [w, b, wg, bb]
+        return _NS(W=wd, S=S, b=bd, tab=None)
 
     def ff_stream(self, w1key, b1key, w2key):
         """(weight stream, packed b1) for rcdm_ff_fused, or None when the library has no fused kernel for this width."""
@@ -447,6 +514,11 @@ def pack_basic_block(pk, b):
     else:
         w.ff1, w.ff1_b = pk.mat_f16(b + "ff.net.0.proj.weight"), pk.vec(b + "ff.net.0.proj.bias")
     w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
+    # deferred LayerNorm operands (rcdm_gemm_lnx): norm1 -> [q;k;v], norm2 -> attn2.to_q, norm3 -> GEGLU projection
+    qkv_keys = tuple(b + f"attn1.to_{n}.weight" for n in "qkv")
+    w.lnx_qkv = pk.lnx_mat(qkv_keys, *w.ln[0], bias=w.qkv1_b) if w.ln[0] is not None else None
+    w.lnx_q2 = pk.lnx_mat((b + "attn2.to_q.weight",), *w.ln[1], bias=w.q2_b) if (w.has_cross and w.ln[1] is not None) else None
+    w.lnx_ff = pk.lnx_geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", *w.ln[2]) if (w.geglu and w.ln[2] is not None) else None
     # row-stationary chains: attn1.to_out + res -> norm2 -> attn2.to_q, and attn2.to_out + res -> norm3 -> ff -> + res
     w.ch_in_qkv = w.ch_o1_q = w.ch_o2_ff = None
     if w.has_cross and w.geglu:
@@ -486,11 +558,14 @@ def pack_motion(pk, p, n_attn):
     for i in range(n_attn):
         a = b + f"attention_blocks.{i}."
         pe = pk.f32(a + "pos_encoder.pe")[0].contiguous() if pk.has(a + "pos_encoder.pe") else None
+        ln_g, ln_b = pk.vec(b + f"norms.{i}.weight"), pk.vec(b + f"norms.{i}.bias")
         w.attn.append(_NS(
-            ln_g=pk.vec(b + f"norms.{i}.weight"), ln_b=pk.vec(b + f"norms.{i}.bias"), pe=pe,
+            ln_g=ln_g, ln_b=ln_b, pe=pe,
             qkv=pk.mat_f16(a + "to_q.weight", a + "to_k.weight", a + "to_v.weight"),
+            lnx=pk.lnx_mat((a + "to_q.weight", a + "to_k.weight", a + "to_v.weight"), ln_g, ln_b, pe=pe),
             o=pk.mat_f16(a + "to_out.0.weight"), o_b=pk.vec(a + "to_out.0.bias")))
     w.ff_ln = (pk.vec(b + "ff_norm.weight"), pk.vec(b + "ff_norm.bias"))
+    w.lnx_ff = pk.lnx_geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", *w.ff_ln)
     w.ff1, w.ff1_b = pk.geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias")
     w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
     w.ff_stream = pk.ff_stream(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight")
@@ -579,9 +654,11 @@ def emit_rowchain(plan, a_in, res, tok, a_bias, ln, pe, stream, tail, out, rows_
     plan.last_gemm = None
 
 
-def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None):
+def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None, tok_stat=None, lnx=None):
     """x += FeedForward_geglu(LayerNorm(x))  (attention.py:514 / motion_module.py:243), in place on tok.
-    stream: (fragment-major weight stream, packed b1) of Packer.ff_stream, or None for the unfused chain."""
+    stream: (fragment-major weight stream, packed b1) of Packer.ff_stream, or None for the unfused chain.
+    tok_stat / lnx: row statistics of tok from the GEMM that wrote it + Packer.lnx_geglu operands — the LayerNorm then
+    rides in the GEGLU projection's epilogue (deferred LayerNorm)."""
     if stream is not None and M >= CHAIN_MIN_ROWS:
         ws, b1p = stream
         d = hip.FFDesc(M, C, tok.ld, tok.ld, 1e-5)
@@ -593,17 +670,23 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None)
         plan.n_launch += 1
         plan.last_gemm = None
         return
-    emit_layernorm(plan, tok, ln_g, ln_b, a)
     gg = plan.rows("geglu", M, 4 * C)
-    emit_gemm(plan, a, ff1, 8 * C, C, gg, bias=ff1_b, geglu=True)
+    if tok_stat is not None and lnx is not None and gemm_lnx_ok(M, 8 * C, C, tok.ld, gg.ld, geglu=True):
+        emit_gemm(plan, tok, lnx.W, 8 * C, C, gg, bias=lnx.b, geglu=True, lnx=(tok_stat, lnx.S))
+    else:
+        emit_layernorm(plan, tok, ln_g, ln_b, a)
+        emit_gemm(plan, a, ff1, 8 * C, C, gg, bias=ff1_b, geglu=True)
     emit_gemm(plan, gg, ff2, C, 4 * C, tok, bias=ff2_b, residual=tok)
 
 
-def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False, ctx_img=None, pre=None, post=None):
+def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False, ctx_img=None, pre=None, post=None,
+                     tok_stat=None):
     """BasicTransformerBlock.forward (src/models/attention.py:479-526) in place on tok [n_seq*Lq][C]:
     h += attn1(LN1(h)); h += attn2(LN2(h), ctx); h += FF(LN3(h)).  ctx_kv: Rows [n_seq*L][2C] = [K | V] of the context.
     shared_half: the two halves of tok (the CFG halves of a denoising step) hold IDENTICAL rows on entry — everything up
-    to the query projection of the cross-attention is then computed on the first half only and stored to both."""
+    to the query projection of the cross-attention is then computed on the first half only and stored to both.
+    tok_stat: row statistics of tok from the GEMM that wrote it (emit_gemm(stat=True)); with them, and below the chain
+    kernels' row count, the three LayerNorms are deferred into the epilogues of the GEMMs behind them (rcdm_gemm_lnx)."""
     C, M = w.C, n_seq * Lq
     d_head = C // heads
     ns, Ms, dup = n_seq, M, 0
@@ -617,18 +700,27 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
     big = M >= CHAIN_MIN_ROWS
     if pre is not None:
         emit_rowchain(plan, pre[0], None, tok, pre[1], w.ln[0], None, w.ch_in_qkv, 3, qkv, gn=pre[2])
+    elif tok_stat is not None and w.lnx_qkv is not None and gemm_lnx_ok(Ms, 3 * C, C, tok.ld, qkv.ld):
+        emit_gemm(plan, tok.rows(0, Ms), w.lnx_qkv.W, 3 * C, C, qkv, bias=w.lnx_qkv.b, lnx=(tok_stat, w.lnx_qkv.S))
     else:
         emit_layernorm(plan, tok.rows(0, Ms), w.ln[0][0], w.ln[0][1], a.rows(0, Ms))
         emit_gemm(plan, a.rows(0, Ms), w.qkv1, 3 * C, C, qkv, bias=w.qkv1_b)
     emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), ns, heads, Lq, Lq, d_head, ao.rows(0, Ms))
     chain_q = w.has_cross and w.ch_o1_q is not None and not shared_half and big
+    want_ff = LNX and not big and w.geglu and w.lnx_ff is not None          # statistics for norm3 -> GEGLU
+    want_q2 = LNX and not big and w.has_cross and w.lnx_q2 is not None     # statistics for norm2 -> attn2.to_q
+    st = None
     if not chain_q:
-        emit_gemm(plan, ao.rows(0, Ms), w.o1, C, C, tok.rows(0, Ms), bias=w.o1_b, residual=tok.rows(0, Ms), dup_rows=dup)
+        st = emit_gemm(plan, ao.rows(0, Ms), w.o1, C, C, tok.rows(0, Ms), bias=w.o1_b, residual=tok.rows(0, Ms), dup_rows=dup,
+                       stat=want_q2 or (want_ff and not w.has_cross))
     if w.has_cross:
         # cross-attention over the L context rows of that sequence
         qc = plan.rows("qkv", M, C)
         if chain_q:   # attn1.to_out + residual -> norm2 -> attn2.to_q in one launch
             emit_rowchain(plan, ao, tok, tok, w.o1_b, w.ln[1], None, w.ch_o1_q, 1, qc)
+        elif st is not None and w.lnx_q2 is not None and gemm_lnx_ok(Ms, C, C, tok.ld, qc.ld, dup_rows=dup):
+            emit_gemm(plan, tok.rows(0, Ms), w.lnx_q2.W, C, C, qc.rows(0, Ms), bias=w.lnx_q2.b, dup_rows=dup,
+                      lnx=(st, w.lnx_q2.S))
         else:
             emit_layernorm(plan, tok.rows(0, Ms), w.ln[1][0], w.ln[1][1], a.rows(0, Ms))
             emit_gemm(plan, a.rows(0, Ms), w.q2, C, C, qc.rows(0, Ms), bias=w.q2_b, dup_rows=dup)
@@ -642,9 +734,10 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
         if w.ch_o2_ff is not None and big:   # attn2.to_out + residual -> norm3 -> ff -> + residual in one launch
             emit_rowchain(plan, ao, tok, tok, w.o2_b, w.ln[2], None, w.ch_o2_ff, 0, tok, b2=w.ff2_b)
             return
-        emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok)
+        st = emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok, stat=want_ff)
     if w.geglu:
-        emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, M, C, stream=w.ff_stream)
+        emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, M, C, stream=w.ff_stream,
+                tok_stat=st if st is not None and st.M >= M else None, lnx=w.lnx_ff)
     else:   # FeedForward("gelu"): Linear -> exact GELU -> Linear (stage-1 prior blocks)
         emit_layernorm(plan, tok, w.ln[2][0], w.ln[2][1], a)
         hid = plan.rows("geglu", M, 4 * C)
@@ -660,7 +753,7 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     n_s, M_s = (g.n_img // 2, g.M // 2) if shared_half else (g.n_img, g.M)
     a = plan.rows("norm", g.M, C)
     tok = plan.rows("tok", g.M, C)
-    pre = None
+    pre, tok_stat = None, None
     if w.ch_in_qkv is not None and not shared_half and g.M >= CHAIN_MIN_ROWS:
         if CHAIN_GN and g.hw % 16 == 0 and g.hw >= 160:   # the norm's apply rides too: only its statistics are launched
             pre = (x, w.proj_in_b, emit_groupnorm_stats(plan, x, n_s, g.hw, w.gn_g, w.gn_b, 1e-6, groups))
@@ -669,11 +762,12 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
             pre = (a, w.proj_in_b, None)       # proj_in rides with norm1 + qkv (emit_basic_block)
     else:
         emit_groupnorm(plan, x.rows(0, M_s), n_s, g.hw, w.gn_g, w.gn_b, 1e-6, False, a.rows(0, M_s), groups)
-        emit_gemm(plan, a.rows(0, M_s), w.proj_in, C, C, tok.rows(0, M_s), bias=w.proj_in_b)
+        tok_stat = emit_gemm(plan, a.rows(0, M_s), w.proj_in, C, C, tok.rows(0, M_s), bias=w.proj_in_b,
+                             stat=LNX and g.M < CHAIN_MIN_ROWS)
     post = (w.ch_o2_ffz, x, w.proj_out_b, out) if (getattr(w, "ch_o2_ffz", None) is not None and w.has_cross and
                                                    g.M >= CHAIN_MIN_ROWS) else None
     emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img, pre=pre,
-                     post=post)
+                     post=post, tok_stat=tok_stat)
     if post is None:
         emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
 
@@ -719,15 +813,26 @@ def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
         emit_rowchain(plan, ao, tok, tok, a1.o_b, w.ff_ln, None, w.chains[2], 0, tok, b2=w.ff2_b)
         emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
         return
-    emit_gemm(plan, a, w.proj_in, C, C, tok, bias=w.proj_in_b)
+    # separate launches; the LayerNorms (+ positional encoding) deferred into the q | k | v / GEGLU epilogues (rcdm_gemm_lnx)
+    want_stat = LNX and g.M < CHAIN_MIN_ROWS
+    st = emit_gemm(plan, a, w.proj_in, C, C, tok, bias=w.proj_in_b, stat=want_stat)
     for at in w.attn:
-        emit_layernorm(plan, tok, at.ln_g, at.ln_b, a, pe=at.pe, rows_per_frame=g.hw, frames=g.f)
         qkv = plan.rows("qkv", g.M, 3 * C)
-        emit_gemm(plan, a, at.qkv, 3 * C, C, qkv)
+        lx = at.lnx
+        if st is not None and lx is not None and gemm_lnx_ok(g.M, 3 * C, C, tok.ld, qkv.ld) and (at.pe is None or g.f <= at.pe.shape[0]):
+            if at.pe is not None:   # (LayerNorm(x) + pe_f) W^T: the per-frame row table, one row per (sample, frame)
+                tab = lx.tab[:g.f].repeat(g.b, 1).contiguous()
+                emit_gemm(plan, tok, lx.W, 3 * C, C, qkv, rowvec=(tab, 0, 3 * C, g.hw), lnx=(st, lx.S))
+            else:
+                emit_gemm(plan, tok, lx.W, 3 * C, C, qkv, bias=lx.b, lnx=(st, lx.S))
+        else:
+            emit_layernorm(plan, tok, at.ln_g, at.ln_b, a, pe=at.pe, rows_per_frame=g.hw, frames=g.f)
+            emit_gemm(plan, a, at.qkv, 3 * C, C, qkv)
         ao = plan.rows("attn_out", g.M, C)
         emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)
-        emit_gemm(plan, ao, at.o, C, C, tok, bias=at.o_b, residual=tok)
-    emit_ff(plan, tok, w.ff_ln[0], w.ff_ln[1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, g.M, C, stream=w.ff_stream)
+        st = emit_gemm(plan, ao, at.o, C, C, tok, bias=at.o_b, residual=tok, stat=want_stat)
+    emit_ff(plan, tok, w.ff_ln[0], w.ff_ln[1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, g.M, C, stream=w.ff_stream, tok_stat=st,
+            lnx=w.lnx_ff)
     emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
 
 

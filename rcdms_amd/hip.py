@@ -31,6 +31,11 @@ class LnFuse(C.Structure):
                 ("rows_per_frame", C.c_int32), ("frames", C.c_int32), ("eps", C.c_float)]
 
 
+class Lnx(C.Structure):
+    _fields_ = [("stat_out", C.c_void_p), ("stat_parts", C.c_int32), ("stat_in", C.c_void_p), ("parts_in", C.c_int32),
+                ("colsum", C.c_void_p), ("eps", C.c_float), ("C", C.c_int32)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("n_img", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
                 ("c_in", C.c_int32), ("c_out", C.c_int32), ("stride", C.c_int32),
@@ -80,6 +85,8 @@ SYMBOLS = {
     "rcdm_last_hip_error": (C.c_int, []),
     "rcdm_last_hip_error_string": (C.c_char_p, []),
     "rcdm_gemm_ln": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(LnFuse), _P, _P, _P, _P, _P, _P]),
+    "rcdm_gemm_stat_parts": (C.c_int, [C.POINTER(GemmDesc)]),
+    "rcdm_gemm_lnx": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(Lnx), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_gemm_workspace_bytes": (_SZ, [C.POINTER(GemmDesc)]),
     "rcdm_set_igemm_variant": (C.c_int, [_I]),
     "rcdm_set_igemm_pingpong": (C.c_int, [_I]),
@@ -237,6 +244,15 @@ def softmax_rows(M, N, ldx, ldy, scale, x, y, stream=None):
 def gemm_ln(desc, ln, a, w, bias, residual, out, stream=None):
     _check(load().rcdm_gemm_ln(C.byref(desc), C.byref(ln), a, w, bias, residual, out,
                                stream_ptr() if stream is None else stream), "rcdm_gemm_ln")
+
+
+def gemm_stat_parts(desc):
+    return int(load().rcdm_gemm_stat_parts(C.byref(desc)))
+
+
+def gemm_lnx(desc, lnx, a, w, bias, rowvec, residual, out, workspace, workspace_bytes, stream=None):
+    _check(load().rcdm_gemm_lnx(C.byref(desc), C.byref(lnx), a, w, bias, rowvec, residual, out, workspace, workspace_bytes,
+                                stream_ptr() if stream is None else stream), "rcdm_gemm_lnx")
 
 
 def flash_attn(desc, q, k, v, out, stream=None):
