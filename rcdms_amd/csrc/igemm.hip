@@ -29,7 +29,7 @@
 #include "common.h"
 #include "igemm_args.h"
 #ifndef RCDM_LNX_ABLATE
-#define RCDM_LNX_ABLATE 0   // debug builds (tools/lnx_bench.py): 1 = no partial-statistics loads, 2 = no S / bias vectors in the items
+#define RCDM_LNX_ABLATE 0   // debug builds (tools/lnx_bench.py): 1 = no partial-statistics loads
 #endif
 
 namespace {
@@ -112,7 +112,12 @@ constexpr int TRACE_SLOTS = 4;
 
 template <int TAPS, int BM_, int BN_, int WM, int WN, int NSTAGE, bool E16, int LX = 0>  // LX: deferred-LayerNorm epilogues (rcdm_gemm_lnx) compiled in: 1 = row statistics only, 2 = consumer (+ statistics)
 // (second launch bound = waves per SIMD the tile's LDS footprint allows: 4 blocks of 64x64, 3 of 128x64, 2 of 128x128 per CU)
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM_ * BN_ <= 64 * 64 && NSTAGE == 2) ? 4 : (WM * WN == 4 && BM_ * BN_ <= 128 * 64) ? 3 : 2)
+#ifdef RCDM_DMA_MINW2   // A/B builds: the round-3 bound (2 waves per SIMD for every tile)
+#define RCDM_DMA_MINW(wm, wn, bm, bn, ns) 2
+#else
+#define RCDM_DMA_MINW(wm, wn, bm, bn, ns) (((wm) * (wn) == 4 && (bm) * (bn) <= 64 * 64 && (ns) == 2) ? 4 : ((wm) * (wn) == 4 && (bm) * (bn) <= 128 * 64) ? 3 : 2)
+#endif
+__global__ __launch_bounds__(WM * WN * 64, RCDM_DMA_MINW(WM, WN, BM_, BN_, NSTAGE))
 void igemm_dma_kernel(const IgemmArgs p) {
   constexpr int NW = WM * WN;             // waves
   constexpr int FM = BM_ / WM / 32;       // pixel fragments per wave
@@ -132,7 +137,8 @@ void igemm_dma_kernel(const IgemmArgs p) {
   constexpr int LTPR = (WM * WN * 64) / BM_;
   static_assert(!LXC || LTPR == 1 || LTPR == 2 || LTPR == 4, "threads per row of the LayerNorm table");
   float* ltab = (float*)(smem + NSTAGE * (BM_ + BN_) * 128);
-  const bool lnx_k = LXC && p.lnx_stat != nullptr;
+  float* lvS = ltab + 2 * BM_;   // [BN] S of the tile's channels
+  constexpr bool lnx_k = LXC;   // the (LX & 2) instantiation is only launched for consumers (p.lnx_stat != nullptr)
 
   const int ntiles = p.tilesM * p.tilesN;
   const int G = gridDim.x;
@@ -278,6 +284,22 @@ void igemm_dma_kernel(const IgemmArgs p) {
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < total) issue_next();
+  // deferred LayerNorm: this thread's share of the NEXT tile's row statistics -> (rstd, mean rstd), and its 4 entries of S.
+  // Fetched where registers are free and a memory wait follows anyway (here: behind the prologue DMA; for later tiles of a
+  // persistent block: at the end of the previous epilogue); written to the LDS table after the tile's first barrier.
+  f32x2 lx_rs = {1.f, 0.f};
+  f32x4 lx_s4 = {0.f, 0.f, 0.f, 0.f};
+  auto lx_fetch = [&](int m0, int n0) __attribute__((always_inline)) {
+    const int lm = m0 + t / LTPR;
+    float r_ = 1.f, m_ = 0.f;
+#if !(RCDM_LNX_ABLATE & 1)
+    lnx_row<LTPR, kLnxMaxParts>(p.lnx_stat, lm, lm < p.M, p.lnx_parts, t % LTPR, p.lnx_invC, p.lnx_eps, r_, m_);
+#endif
+    lx_rs = f32x2{r_, m_};
+    lx_s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t < BN_ / 4 && n0 + 4 * t < p.N) lx_s4 = *(const f32x4*)(p.lnx_S + n0 + 4 * t);
+  };
+  if constexpr (LXC) lx_fetch(cm0, cn0);
   int c_ks = 0, c_tile = 0;   // k-step / tile being computed
   int c_stage = 0;            // ring slot being computed
   int post_epi = 0;           // 2: an epilogue just ran (operands of the next step already landed), 1: its stores may be in flight
@@ -288,12 +310,7 @@ void igemm_dma_kernel(const IgemmArgs p) {
     // younger steps may still be in flight); the barrier makes everybody's visible and also guarantees every
     // wave is done reading the slot of step g-1, which the issue below refills
     const int younger = min(NSTAGE - 2, total - 1 - g);
-    LnxRow<LTPR, LXC ? kLnxMaxParts : 1> lrow;
     const bool lx_now = lnx_k && c_ks == 0;
-    if constexpr (LXC) if (lx_now) {
-      const int lm = cm0 + t / LTPR;
-      lrow.load(p.lnx_stat, lm, lm < p.M, p.lnx_parts, t % LTPR);
-    }
     if (post_epi == 2) {
       // first step of a new tile: every DMA piece issued so far was waited for inside the epilogue, BEFORE its output
       // stores were issued — nothing to wait for here, and the stores' round trip to L2 (vmcnt counts them, and they
@@ -311,11 +328,8 @@ void igemm_dma_kernel(const IgemmArgs p) {
     }
     __builtin_amdgcn_s_barrier();
     if constexpr (LXC) if (lx_now) {   // (after the barrier: the previous tile's epilogue is done reading the table)
-      float rs_ = 1.f, mr_ = 0.f;
-#if !(RCDM_LNX_ABLATE & 1)
-      lrow.finish(p.lnx_invC, p.lnx_eps, rs_, mr_);
-#endif
-      if (t % LTPR == 0) *(f32x2*)(ltab + 2 * (t / LTPR)) = f32x2{rs_, mr_};
+      if (t % LTPR == 0) *(f32x2*)(ltab + 2 * (t / LTPR)) = lx_rs;
+      if (t < BN_ / 4) *(f32x4*)(lvS + 4 * t) = lx_s4;
     }
     // 8-wave blocks put two waves on every SIMD, released by the same barrier: if both issued their DMA pieces first
     // (each piece stalls the issuing wave for ~100 cycles) the SIMD's matrix pipe would idle through both bursts.
@@ -348,6 +362,29 @@ void igemm_dma_kernel(const IgemmArgs p) {
     // coalesced 16-byte-per-lane store phase; the DMA of the next tile's first step keeps flowing into the other
     // stage.  Raw s_barrier + lgkmcnt only: a __syncthreads() here would drain that DMA (vmcnt(0)).
     c_ks = 0;
+    if constexpr (E16 && (LX & 2) != 0) {
+      // deferred LayerNorm: x W'^T of the raw rows -> rstd acc - (mean rstd) S = LayerNorm(x) W'^T, on the accumulators,
+      // before any of the epilogue's prefetches is live; everything below (bias b', row table, GEGLU, residual) runs unchanged
+      // on top.  The table was written behind the first k-step's barrier: a one-step tile needs one more barrier here.
+      if (nkl == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      f32x2 rs[FM];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) rs[j] = *(const f32x2*)(ltab + 2 * ((wm * FM + j) * 32 + lr));
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 s4 = *(const f32x4*)(lvS + (wn * FN + i) * 32 + 8 * q + 4 * hi);   // S of this quad's 4 channels
+#pragma unroll
+          for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[i][j][4 * q + e] = __builtin_fmaf(acc[i][j][4 * q + e], rs[j].x, -rs[j].y * s4[e]);
+        }
+    }
     if constexpr (E16) {
       // ---- f16 staging (every launch without split-K): the accumulators are rounded to f16 (the reference's fp16
       // Linear / Conv outputs are rounded at the same point, give or take the bias) and staged as [rows][BN] halfs:
@@ -395,15 +432,8 @@ void igemm_dma_kernel(const IgemmArgs p) {
       }
       // deferred LayerNorm of the A rows (rcdm_gemm_lnx): LTPR threads per tile row sum that row's partial statistics;
       // (rstd, mean rstd) go to a [BM][2] table behind the ring, published by the staging barrier of the first pass
-      const bool lnx = LXC && p.lnx_stat != nullptr;
+      constexpr bool lnx = LXC;
       const bool stat_on = LX != 0 && p.stat_out != nullptr;
-      float sA[LXC ? 8 : 1], sB[LXC ? 8 : 1];
-#pragma unroll
-      for (int e = 0; e < (LXC ? 8 : 1); ++e) sA[e] = sB[e] = 0.f;
-      if constexpr (LXC) if (lnx && pn_ok) {
-        load8(p.lnx_S + pn, sA);
-        if (geglu) load8(p.lnx_S + pn + kGegluGroup, sB);
-      }
       const int stat_tn = cn0 / BN_;
       const int dup_rows = p.dup ? (int)(p.dup / p.ldc) : 0;
       if (WHOLE && !geglu) {
@@ -473,16 +503,7 @@ void igemm_dma_kernel(const IgemmArgs p) {
                 const int m = mbase + gr0 + (it0 + k) * G_RPI;
                 if (m < p.M && pn_ok) {
                   Pack16 o;
-                  if constexpr (LXC) {
-                    if (lnx) {
-                      const f32x2 rs = *(const f32x2*)(ltab + 2 * (m - cm0));
-                      o.u = geglu8_lnx(hh[k].u, gg[k].u, bA, bB, sA, sB, rs.x, rs.y, sc);
-                    } else {
-                      o.u = geglu8(hh[k].u, gg[k].u, bA, bB, sc);
-                    }
-                  } else {
-                    o.u = geglu8(hh[k].u, gg[k].u, bA, bB, sc);
-                  }
+                  o.u = geglu8(hh[k].u, gg[k].u, bA, bB, sc);
                   *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
                   if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + oc + p.dup) = o.u;
                 }
@@ -515,18 +536,11 @@ void igemm_dma_kernel(const IgemmArgs p) {
                   const Pack16& rr = resv[WHOLE ? ps : 0][it];
                   Pack16 o;
                   if (gelu_on || (has_rv && !rv_pair)) {
-                    // rare forms (stage-1 GELU feed-forward; row vector with fewer rows per sample than the tile) and the
-                    // deferred LayerNorm of the A rows: plain fp32 arithmetic
+                    // rare forms (stage-1 GELU feed-forward; row vector with fewer rows per sample than the tile): plain
+                    // fp32 arithmetic
                     float v[8];
-                    if (LXC && lnx) {
-                      const f32x2 rs = *(const f32x2*)(ltab + 2 * (m - cm0));
 #pragma unroll
-                      for (int e = 0; e < 8; ++e)
-                        v[e] = __builtin_fmaf((float)hh[k].e[e], rs.x, __builtin_fmaf(-rs.y, sA[LXC ? e : 0], bA[e]));
-                    } else {
-#pragma unroll
-                      for (int e = 0; e < 8; ++e) v[e] = (float)hh[k].e[e] + bA[e];
-                    }
+                    for (int e = 0; e < 8; ++e) v[e] = (float)hh[k].e[e] + bA[e];
                     if (has_rv && rv_pair) {
                       const bool second = m >= m_switch;
 #pragma unroll
@@ -544,22 +558,11 @@ void igemm_dma_kernel(const IgemmArgs p) {
                     for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + (float)rr.e[e]) * sc);
                   } else {
                     const bool second = m >= m_switch;
-                    // deferred LayerNorm: h * (rstd sc) + ((bias + row vector) sc - (mean rstd sc) S), same two-instruction form
-                    float s_eff = sc, nmr = 0.f;
-                    if (LXC && lnx) {
-                      const f32x2 rs = *(const f32x2*)(ltab + 2 * (m - cm0));
-                      s_eff = rs.x * sc;
-                      nmr = -rs.y * sc;
-                    }
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                      float c0 = second ? cB[2 * d] : cA[2 * d], c1 = second ? cB[2 * d + 1] : cA[2 * d + 1];
-                      if (LXC && lnx && !(RCDM_LNX_ABLATE & 2)) {
-                        c0 = __builtin_fmaf(nmr, sA[LXC ? 2 * d : 0], c0);
-                        c1 = __builtin_fmaf(nmr, sA[LXC ? 2 * d + 1 : 0], c1);
-                      }
-                      const float t0 = mix_f16_f32(hh[k].v[d], 0, s_eff, c0);
-                      const float t1 = mix_f16_f32(hh[k].v[d], 1, s_eff, c1);
+                      const float c0 = second ? cB[2 * d] : cA[2 * d], c1 = second ? cB[2 * d + 1] : cA[2 * d + 1];
+                      const float t0 = mix_f16_f32(hh[k].v[d], 0, sc, c0);
+                      const float t1 = mix_f16_f32(hh[k].v[d], 1, sc, c1);
                       o.v[d] = mix_f16_pack(rr.v[d], sc, t0, t1);
                     }
                   }
@@ -643,7 +646,10 @@ void igemm_dma_kernel(const IgemmArgs p) {
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     ++c_tile;
     post_epi = 2;
-    if (c_tile < my_tiles) tile_of(c_tile, cm0, cn0);
+    if (c_tile < my_tiles) {
+      tile_of(c_tile, cm0, cn0);
+      if constexpr (LXC) lx_fetch(cm0, cn0);
+    }
     if (p.trace) ts_epi += __builtin_amdgcn_s_memtime() - te0;
   }
   if (p.trace && t == 0) {
@@ -896,7 +902,7 @@ void set_lds(K kernel, int bytes) {
 
 template <int TAPS>
 int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  constexpr int LTAB = 2048;                       // [BM][2] floats behind the ring: the deferred-LayerNorm row table
+  constexpr int LTAB = 3072;                       // behind the ring, deferred LayerNorm: [BM][2] floats (rstd, mean rstd) + [BN] floats S
   constexpr int LDS_128 = 2 * (128 + 128) * 128 + LTAB;   // 64 KB  (two blocks per CU)
   constexpr int LDS_256 = 2 * (256 + 256) * 128 + LTAB;   // 128 KB
   constexpr int LDS_64 = 2 * (64 + 64) * 128 + LTAB;      // 32 KB  (four blocks per CU)
