@@ -93,8 +93,9 @@ int rcdm_gemm_ln(const rcdm_gemm_desc* d, const rcdm_ln_fuse* ln, const void* A,
  * own and without the normalised tensor ever existing in HBM.  With W' = W diag(gamma) and b' = b + W beta (folded once, at
  * pack time; for pos_encoder a per-frame row table b'_f = b' + W pe_f passed as `rowvec`):
  *     LayerNorm(x) W^T + b  =  rstd (x W'^T) - (rstd mean) S + b',      S[n] = sum_c f16(W'[n][c]).
- *   PRODUCER (the GEMM that writes the rows x, e.g. to_out + residual or proj_in): stat_out[m][stat_parts] (float2 each)
- *     = (sum, sum of squares) of the f16 values it stores to row m, one slot per column tile of its launch.  stat_parts
+ *   PRODUCER (the GEMM that writes the rows x, e.g. to_out + residual or proj_in): stat_out[slot][m] (float2 each, slot-major:
+ *     a consumer's lanes read consecutive rows of one slot) = (sum, sum of squares) of the f16 values it stores to row m,
+ *     one slot per column tile of its launch.  stat_parts
  *     must equal rcdm_gemm_stat_parts(d) (the column-tile count of the tile shape a statistics-producing launch of this
  *     shape uses; RCDM_ESHAPE otherwise).  Plain / bias / row-vector / residual epilogues, no GEGLU, no split-K.
  *   CONSUMER (A = the RAW rows x, W = f16(W'), bias = b', colsum = S in the packed column order of W): stat_in / parts_in
@@ -103,10 +104,12 @@ int rcdm_gemm_ln(const rcdm_gemm_desc* d, const rcdm_ln_fuse* ln, const void* A,
  *     GELU / GEGLU / residual.  Every epilogue form, no split-K; parts_in <= 20.
  *   One call may be both.  Both sides NULL = rcdm_gemm. */
 typedef struct {
-  float* stat_out;            /* producer: [M (+ dup rows)][stat_parts][2] fp32, or NULL */
+  float* stat_out;            /* producer: slot-major [stat_parts][stat_out_rows][2] fp32, or NULL */
   int32_t stat_parts;
-  const float* stat_in;       /* consumer: [M][parts_in][2] fp32, or NULL */
+  int32_t stat_out_rows;      /* rows per slot plane of stat_out: >= M + dup_rows */
+  const float* stat_in;       /* consumer: [parts_in][stat_in_rows][2] fp32 (the producer's buffer), or NULL */
   int32_t parts_in;
+  int32_t stat_in_rows;       /* rows per slot plane of stat_in (= the producer's stat_out_rows) */
   const float* colsum;        /* consumer: S [N] fp32 (16-byte aligned) */
   float eps;                  /* LayerNorm eps (1e-5) */
   int32_t C;                  /* LayerNorm width = K of the consumer */

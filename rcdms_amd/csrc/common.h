@@ -154,12 +154,14 @@ struct LnxRow {
   f32x2 v[NL];
   // every load is issued unconditionally at a clamped index and zeroed by a select afterwards: a load under a
   // per-element runtime condition makes hipcc branch around each one and wait for it (NL dependent L2 round trips)
-  __device__ __forceinline__ void load(const float* stat, int m, bool live, int parts, int sub) {
-    const f32x2* row = (const f32x2*)stat + (size_t)(live ? m : 0) * parts;
+  // layout: slot-major, stat[slot][ld rows] of (sum, sum of squares) — the lanes of a load instruction (consecutive rows
+  // of one slot) read consecutive 8-byte pairs
+  __device__ __forceinline__ void load(const float* stat, int ld, int m, bool live, int parts, int sub) {
+    const f32x2* row = (const f32x2*)stat + (live ? m : 0);
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int idx = sub + j * TPR;
-      v[j] = row[min(idx, parts - 1)];
+      v[j] = row[(size_t)min(idx, parts - 1) * ld];
     }
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
@@ -190,15 +192,15 @@ struct LnxRow {
 // (rstd, mean rstd) of row m with the load count sized to the slot count: <= 8 slots (C <= 1024 behind 128-wide producer
 // tiles) take the short form
 template <int TPR, int MAXP>
-__device__ __forceinline__ void lnx_row(const float* stat, int m, bool live, int parts, int sub, float invC, float eps,
+__device__ __forceinline__ void lnx_row(const float* stat, int ld, int m, bool live, int parts, int sub, float invC, float eps,
                                         float& rstd, float& mr) {
   if (parts <= 8) {   // wave-uniform
     LnxRow<TPR, 8> r;
-    r.load(stat, m, live, parts, sub);
+    r.load(stat, ld, m, live, parts, sub);
     r.finish(invC, eps, rstd, mr);
   } else {
     LnxRow<TPR, MAXP> r;
-    r.load(stat, m, live, parts, sub);
+    r.load(stat, ld, m, live, parts, sub);
     r.finish(invC, eps, rstd, mr);
   }
 }

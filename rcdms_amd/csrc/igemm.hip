@@ -29,7 +29,7 @@
 #include "common.h"
 #include "igemm_args.h"
 #ifndef RCDM_LNX_ABLATE
-#define RCDM_LNX_ABLATE 0   // debug builds (tools/lnx_bench.py): 1 = no partial-statistics loads
+#define RCDM_LNX_ABLATE 0   // debug builds (tools/lnx_bench.py): 1 = no partial-statistics loads, 64 = no accumulator transform, 128 = no table write, 256 = no producer statistics
 #endif
 
 namespace {
@@ -264,6 +264,19 @@ void igemm_dma_kernel(const IgemmArgs p) {
   if (p.trace) ts0 = __builtin_amdgcn_s_memtime();
   int cm0, cn0;               // tile being computed
   tile_of(0, cm0, cn0);
+  // deferred LayerNorm: this thread's share of the first tile's row statistics and its 4 entries of S are requested
+  // FIRST — the loader set-up and the prologue DMA below cover their round trip (asked for behind the DMA they cost the
+  // 16x16-level attn2.to_q +2.3 us: tools/lnx_bench.py, -DRCDM_LNX_ABLATE=1)
+  f32x2 lx_rs = {1.f, 0.f};
+  f32x4 lx_s4 = {0.f, 0.f, 0.f, 0.f};
+  LnxRow<LTPR, LXC ? kLnxMaxParts : 1> lx_row0;
+  if constexpr (LXC) {
+    const int lm = cm0 + t / LTPR;
+#if !(RCDM_LNX_ABLATE & 1)
+    lx_row0.load(p.lnx_stat, p.lnx_ld, lm, lm < p.M, p.lnx_parts, t % LTPR);
+#endif
+    if (t < BN_ / 4 && cn0 + 4 * t < p.N) lx_s4 = *(const f32x4*)(p.lnx_S + cn0 + 4 * t);
+  }
   setup_loader(cm0, cn0);
   const int total = my_tiles * nkl;
   int i_tile = 0, i_ks = 0;   // next (tile, k-step) to issue
@@ -287,19 +300,23 @@ void igemm_dma_kernel(const IgemmArgs p) {
   // deferred LayerNorm: this thread's share of the NEXT tile's row statistics -> (rstd, mean rstd), and its 4 entries of S.
   // Fetched where registers are free and a memory wait follows anyway (here: behind the prologue DMA; for later tiles of a
   // persistent block: at the end of the previous epilogue); written to the LDS table after the tile's first barrier.
-  f32x2 lx_rs = {1.f, 0.f};
-  f32x4 lx_s4 = {0.f, 0.f, 0.f, 0.f};
   auto lx_fetch = [&](int m0, int n0) __attribute__((always_inline)) {
     const int lm = m0 + t / LTPR;
     float r_ = 1.f, m_ = 0.f;
 #if !(RCDM_LNX_ABLATE & 1)
-    lnx_row<LTPR, kLnxMaxParts>(p.lnx_stat, lm, lm < p.M, p.lnx_parts, t % LTPR, p.lnx_invC, p.lnx_eps, r_, m_);
+    lnx_row<LTPR, kLnxMaxParts>(p.lnx_stat, p.lnx_ld, lm, lm < p.M, p.lnx_parts, t % LTPR, p.lnx_invC, p.lnx_eps, r_, m_);
 #endif
     lx_rs = f32x2{r_, m_};
     lx_s4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < BN_ / 4 && n0 + 4 * t < p.N) lx_s4 = *(const f32x4*)(p.lnx_S + n0 + 4 * t);
   };
-  if constexpr (LXC) lx_fetch(cm0, cn0);
+#if !(RCDM_LNX_ABLATE & 1)
+  if constexpr (LXC) {
+    float r_, m_;
+    lx_row0.finish(p.lnx_invC, p.lnx_eps, r_, m_);
+    lx_rs = f32x2{r_, m_};
+  }
+#endif
   int c_ks = 0, c_tile = 0;   // k-step / tile being computed
   int c_stage = 0;            // ring slot being computed
   int post_epi = 0;           // 2: an epilogue just ran (operands of the next step already landed), 1: its stores may be in flight
@@ -327,7 +344,7 @@ void igemm_dma_kernel(const IgemmArgs p) {
       post_epi = 0;
     }
     __builtin_amdgcn_s_barrier();
-    if constexpr (LXC) if (lx_now) {   // (after the barrier: the previous tile's epilogue is done reading the table)
+    if constexpr (LXC && !(RCDM_LNX_ABLATE & 128)) if (lx_now) {   // (after the barrier: the previous tile's epilogue is done reading the table)
       if (t % LTPR == 0) *(f32x2*)(ltab + 2 * (t / LTPR)) = lx_rs;
       if (t < BN_ / 4) *(f32x4*)(lvS + 4 * t) = lx_s4;
     }
@@ -362,7 +379,7 @@ void igemm_dma_kernel(const IgemmArgs p) {
     // coalesced 16-byte-per-lane store phase; the DMA of the next tile's first step keeps flowing into the other
     // stage.  Raw s_barrier + lgkmcnt only: a __syncthreads() here would drain that DMA (vmcnt(0)).
     c_ks = 0;
-    if constexpr (E16 && (LX & 2) != 0) {
+    if constexpr (E16 && (LX & 2) != 0 && !(RCDM_LNX_ABLATE & 64)) {
       // deferred LayerNorm: x W'^T of the raw rows -> rstd acc - (mean rstd) S = LayerNorm(x) W'^T, on the accumulators,
       // before any of the epilogue's prefetches is live; everything below (bias b', row table, GEGLU, residual) runs unchanged
       // on top.  The table was written behind the first k-step's barrier: a one-step tile needs one more barrier here.
@@ -433,7 +450,7 @@ void igemm_dma_kernel(const IgemmArgs p) {
       // deferred LayerNorm of the A rows (rcdm_gemm_lnx): LTPR threads per tile row sum that row's partial statistics;
       // (rstd, mean rstd) go to a [BM][2] table behind the ring, published by the staging barrier of the first pass
       constexpr bool lnx = LXC;
-      const bool stat_on = LX != 0 && p.stat_out != nullptr;
+      const bool stat_on = LX != 0 && p.stat_out != nullptr && !(RCDM_LNX_ABLATE & 256);
       const int stat_tn = cn0 / BN_;
       const int dup_rows = p.dup ? (int)(p.dup / p.ldc) : 0;
       if (WHOLE && !geglu) {
@@ -520,6 +537,9 @@ void igemm_dma_kernel(const IgemmArgs p) {
 #pragma unroll
           for (int it0 = 0; it0 < P_ITEMS; it0 += RCH) {
             Pack16 hh[RCH];
+            float stv1[RCH], stv2[RCH];
+#pragma unroll
+            for (int k = 0; k < RCH; ++k) stv1[k] = stv2[k] = 0.f;
 #pragma unroll
             for (int k = 0; k < RCH; ++k)
               if (it0 + k < P_ITEMS) {
@@ -531,7 +551,8 @@ void igemm_dma_kernel(const IgemmArgs p) {
               if (it0 + k < P_ITEMS) {
                 const int it = it0 + k;
                 const int m = mbase + pr0 + it * P_RPI;
-                float st1 = 0.f, st2 = 0.f;   // producer side of a deferred LayerNorm: sums over this thread's 8 outputs
+                float& st1 = stv1[k];          // producer side of a deferred LayerNorm: sums over this thread's 8 outputs
+                float& st2 = stv2[k];
                 if (m < p.M && pn_ok) {
                   const Pack16& rr = resv[WHOLE ? ps : 0][it];
                   Pack16 o;
@@ -577,15 +598,26 @@ void igemm_dma_kernel(const IgemmArgs p) {
                     }
                   }
                 }
-                if (stat_on) {   // wave-uniform; every lane of the P_TPR-lane row group takes part in the DPP sums
-                  st1 = group_sum<P_TPR>(st1);
-                  st2 = group_sum<P_TPR>(st2);
-                  if (pc8 == 0 && m < p.M) {
-                    *(f32x2*)(p.stat_out + ((size_t)m * p.stat_parts + stat_tn) * 2) = f32x2{st1, st2};
-                    if (dup_rows) *(f32x2*)(p.stat_out + ((size_t)(m + dup_rows) * p.stat_parts + stat_tn) * 2) = f32x2{st1, st2};
+              }
+            if (stat_on) {
+              // wave-uniform; every lane of the P_TPR-lane row group takes part in the DPP sums.  The batch's 2 RCH reductions
+              // are independent chains the scheduler interleaves; one store per row and column tile
+#pragma unroll
+              for (int k = 0; k < RCH; ++k) {
+                stv1[k] = group_sum<P_TPR>(stv1[k]);
+                stv2[k] = group_sum<P_TPR>(stv2[k]);
+              }
+              if (pc8 == 0) {
+#pragma unroll
+                for (int k = 0; k < RCH; ++k) {
+                  const int m = mbase + pr0 + (it0 + k) * P_RPI;
+                  if (it0 + k < P_ITEMS && m < p.M) {
+                    *(f32x2*)(p.stat_out + ((size_t)stat_tn * p.stat_ld + m) * 2) = f32x2{stv1[k], stv2[k]};
+                    if (dup_rows) *(f32x2*)(p.stat_out + ((size_t)stat_tn * p.stat_ld + m + dup_rows) * 2) = f32x2{stv1[k], stv2[k]};
                   }
                 }
               }
+            }
           }
         }
       }
@@ -1124,11 +1156,14 @@ int rcdm_gemm_lnx(const rcdm_gemm_desc* d, const rcdm_lnx* x, const void* A, con
     if (x->stat_parts <= 0 || ((uintptr_t)x->stat_out & 7)) return RCDM_EINVAL;
     a.stat_out = x->stat_out;
     a.stat_parts = x->stat_parts;
+    a.stat_ld = x->stat_out_rows;
+    if (a.stat_ld < a.M + d->dup_rows) return RCDM_EINVAL;
   }
   if (x->stat_in) {
     if (!x->colsum || x->parts_in <= 0 || x->C <= 0 || ((uintptr_t)x->stat_in & 7) || ((uintptr_t)x->colsum & 15)) return RCDM_EINVAL;
     if (x->parts_in > kLnxMaxParts) return RCDM_ESHAPE;
-    a.lnx_stat = x->stat_in; a.lnx_S = x->colsum; a.lnx_parts = x->parts_in;
+    a.lnx_stat = x->stat_in; a.lnx_S = x->colsum; a.lnx_parts = x->parts_in; a.lnx_ld = x->stat_in_rows;
+    if (a.lnx_ld < a.M) return RCDM_EINVAL;
     a.lnx_invC = 1.0f / (float)x->C; a.lnx_eps = x->eps;
   }
   int variant = 0;

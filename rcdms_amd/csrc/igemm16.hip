@@ -52,6 +52,13 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
     cn0 = tn * BN;
   }
 
+  // deferred LayerNorm of the A rows (rcdm_gemm_lnx): thread t < BM requests row t's partial statistics FIRST — the loader
+  // set-up and the first operand stage cover the round trip — and carries (rstd, mean rstd) in two registers to the epilogue
+  f32x2 lx_pre = {1.f, 0.f};
+  const bool lx_on = TAPS == 1 && !SLAB && p.lnx_stat != nullptr;
+  LnxRow<1, kLnxMaxParts> lx_row0;
+  if (lx_on && t < BM) lx_row0.load(p.lnx_stat, p.lnx_ld, cm0 + t, cm0 + t < p.M, p.lnx_parts, 0);
+
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7FFFFFFF, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
@@ -134,13 +141,9 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   issue(0, 0);
-  // deferred LayerNorm of the A rows (rcdm_gemm_lnx): thread t < BM sums row t's partial statistics now — the loads ride
-  // on the wait for the first operand stage — and carries (rstd, mean rstd) in two registers to the epilogue
-  f32x2 lx_pre = {1.f, 0.f};
-  const bool lx_on = TAPS == 1 && !SLAB && p.lnx_stat != nullptr;
   if (lx_on && t < BM) {
     float r_ = 1.f, m_ = 0.f;
-    lnx_row<1, kLnxMaxParts>(p.lnx_stat, cm0 + t, cm0 + t < p.M, p.lnx_parts, 0, p.lnx_invC, p.lnx_eps, r_, m_);
+    lx_row0.finish(p.lnx_invC, p.lnx_eps, r_, m_);
     lx_pre = f32x2{r_, m_};
   }
   for (int g = 0; g < nkl; ++g) {

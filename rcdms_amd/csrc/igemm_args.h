@@ -34,16 +34,16 @@ struct IgemmArgs {
   f16* ln_out;
   int ln_ld, ln_rpf, ln_frames;
   float ln_eps;
-  // deferred LayerNorm (rcdm_gemm_lnx).  Producer side: stat_out[m][stat_parts] = (sum, sum of squares) of the f16 values
+  // deferred LayerNorm (rcdm_gemm_lnx).  Producer side: stat_out[slot][m] = (sum, sum of squares) of the f16 values
   // this launch stores to row m, one slot per column tile (stat_parts == tilesN).  Consumer side: the A rows are the RAW
   // input x of a LayerNorm whose gamma is folded into W and whose beta into the bias, so LayerNorm(x) W^T =
   // rstd (x W'^T) - rstd mean S, S[n] = sum_c W'[n][c]: lnx_stat holds the producer's partials of the A rows, the epilogue
   // forms (rstd, mean rstd) per row and applies them before bias / row vector / GEGLU / residual.
   float* stat_out;
-  int stat_parts;
+  int stat_parts, stat_ld;      // slot-major: stat_out[slot][stat_ld rows][2]
   const float* lnx_stat;
   const float* lnx_S;
-  int lnx_parts;
+  int lnx_parts, lnx_ld;
   float lnx_invC, lnx_eps;
 };
 constexpr int kLnxMaxParts = 20;   // partial slots per row a consumer can sum (N = 1280 behind 64-wide producer tiles)

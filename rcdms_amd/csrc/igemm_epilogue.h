@@ -66,7 +66,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
         rstd = lx_pre.x;
         mr = lx_pre.y;
       } else if (t < BM) {
-        lnx_row<1, kLnxMaxParts>(p.lnx_stat, cm0 + t, cm0 + t < p.M, p.lnx_parts, 0, p.lnx_invC, p.lnx_eps, rstd, mr);
+        lnx_row<1, kLnxMaxParts>(p.lnx_stat, p.lnx_ld, cm0 + t, cm0 + t < p.M, p.lnx_parts, 0, p.lnx_invC, p.lnx_eps, rstd, mr);
       }
 #endif
       const int vn = cn0 + 4 * t;

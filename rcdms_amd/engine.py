@@ -144,12 +144,13 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
     if stat and LNX and not wsb and not geglu:
         parts = hip.gemm_stat_parts(d)
         if 0 < parts <= LNX_MAX_PARTS:
-            handle = _NS(buf=plan.scratch("rowstat", (A.M + dup_rows) * parts * 8), parts=parts, M=A.M, C=N)
+            handle = _NS(buf=plan.scratch("rowstat", (A.M + dup_rows) * parts * 8), parts=parts, M=A.M, C=N, rows=A.M + dup_rows)
     if lnx is not None:
         assert not wsb, "deferred LayerNorm consumer cannot be a split-K launch (gemm_lnx_ok)"
         assert lnx[0].C == K and lnx[0].M >= A.M
     if handle is not None or lnx is not None:
-        x = hip.Lnx(0, handle.parts if handle else 0, 0, lnx[0].parts if lnx else 0, lnx[1].data_ptr() if lnx else 0, 1e-5, K)
+        x = hip.Lnx(0, handle.parts if handle else 0, handle.rows if handle else 0, 0, lnx[0].parts if lnx else 0,
+                    lnx[0].rows if lnx else 0, lnx[1].data_ptr() if lnx else 0, 1e-5, K)
 
     def op():
         rvp = (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0

@@ -32,8 +32,8 @@ class LnFuse(C.Structure):
 
 
 class Lnx(C.Structure):
-    _fields_ = [("stat_out", C.c_void_p), ("stat_parts", C.c_int32), ("stat_in", C.c_void_p), ("parts_in", C.c_int32),
-                ("colsum", C.c_void_p), ("eps", C.c_float), ("C", C.c_int32)]
+    _fields_ = [("stat_out", C.c_void_p), ("stat_parts", C.c_int32), ("stat_out_rows", C.c_int32), ("stat_in", C.c_void_p),
+                ("parts_in", C.c_int32), ("stat_in_rows", C.c_int32), ("colsum", C.c_void_p), ("eps", C.c_float), ("C", C.c_int32)]
 
 
 class ConvDesc(C.Structure):

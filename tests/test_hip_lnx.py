@@ -27,7 +27,7 @@ def _producer(hip, Ap, Wp, bp, res, M, C, Kp, variant, dup=0):
     assert parts > 0
     x = torch.full((M + dup, C), float("nan"), dtype=torch.float16, device=DEV)
     stat = torch.full(((M + dup) * parts * 2,), float("nan"), dtype=torch.float32, device=DEV)
-    lx = hip.Lnx(stat.data_ptr(), parts, 0, 0, 0, 1e-5, 0)
+    lx = hip.Lnx(stat.data_ptr(), parts, M + dup, 0, 0, 0, 0, 1e-5, 0)
     Ad, Wd, bd, Rd = Ap.half().to(DEV), Wp.half().to(DEV), bp.to(DEV), res.half().to(DEV)
     hip.gemm_lnx(d, lx, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), 0, Rd.data_ptr(), x.data_ptr(), 0, 0)
     torch.cuda.synchronize()
@@ -50,7 +50,7 @@ def test_row_statistics(hiplib, M, C, pvariant):
     xs = x.float().cpu()
     ref = h16(Ap @ Wp.t() + bp + res)
     close(xs, ref)
-    st = stat.cpu().view(M, parts, 2).sum(dim=1)
+    st = stat.cpu().view(parts, M, 2).sum(dim=0)
     assert torch.isfinite(st).all(), "a statistics slot was not written"
     r1, r2 = xs.double().sum(dim=1), (xs.double() ** 2).sum(dim=1)
     e1 = ((st[:, 0].double() - r1).abs() / (xs.double().abs().sum(dim=1) + 1e-6)).max().item()
@@ -126,7 +126,7 @@ def test_gemm_lnx_vs_reference(hiplib, M, C, N, form, shift, cvariant):
     out = torch.full((M, ldc), float("nan"), dtype=torch.float16, device=DEV)
     hip.set_igemm_variant(cvariant)
     d = hip.GemmDesc(M, N, C, C, ldc, 0, epi, rps, N if form == "rowvec" else 0, 1.0, 1, 0)
-    lx = hip.Lnx(0, 0, stat.data_ptr(), parts, Sd.data_ptr(), 1e-5, C)
+    lx = hip.Lnx(0, 0, 0, stat.data_ptr(), parts, M, Sd.data_ptr(), 1e-5, C)
     hip.gemm_lnx(d, lx, x.data_ptr(), Wd.data_ptr(), bias_d, rowvec_d, 0, out.data_ptr(), 0, 0)
     torch.cuda.synchronize()
     hip.set_igemm_variant(-1)
@@ -150,8 +150,8 @@ def test_gemm_lnx_dup_rows_and_both_sides(hiplib):
     x, stat, parts = _producer(hip, Ap, Wp, bp, res, M, C, Kp, -1, dup=M)
     xs = x.float().cpu()
     assert torch.equal(xs[:M], xs[M:]), "dup rows differ"
-    st = stat.cpu().view(2 * M, parts, 2)
-    assert torch.equal(st[:M], st[M:]), "statistics of the dup rows differ"
+    st = stat.cpu().view(parts, 2 * M, 2)
+    assert torch.equal(st[:, :M], st[:, M:]), "statistics of the dup rows differ"
     gamma, beta = 1.0 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
     W = torch.randn(C, C, generator=g) * C ** -0.5
     Wg, S, bf = _fold(W, gamma, beta, None)
@@ -160,14 +160,14 @@ def test_gemm_lnx_dup_rows_and_both_sides(hiplib):
     out = torch.full((2 * M, C), float("nan"), dtype=torch.float16, device=DEV)
     stat2 = torch.full((2 * M * parts2 * 2,), float("nan"), dtype=torch.float32, device=DEV)
     Wd, Sd, bd = Wg.to(DEV), S.to(DEV), bf.to(DEV)
-    lx = hip.Lnx(stat2.data_ptr(), parts2, stat.data_ptr(), parts, Sd.data_ptr(), 1e-5, C)
+    lx = hip.Lnx(stat2.data_ptr(), parts2, 2 * M, stat.data_ptr(), parts, 2 * M, Sd.data_ptr(), 1e-5, C)
     hip.gemm_lnx(d, lx, x.data_ptr(), Wd.data_ptr(), bd.data_ptr(), 0, 0, out.data_ptr(), 0, 0)
     torch.cuda.synchronize()
     ref = torch.nn.functional.layer_norm(xs[:M], (C,), gamma, beta, 1e-5) @ h16(W).t()
     o = out.float().cpu()
     close(o[:M], ref, rel=4e-3, abs_frac=6e-3)
     assert torch.equal(o[:M], o[M:])
-    s2 = stat2.cpu().view(2 * M, parts2, 2).sum(dim=1)
+    s2 = stat2.cpu().view(parts2, 2 * M, 2).sum(dim=0)
     assert torch.allclose(s2[:M, 0], o[:M].sum(dim=1), rtol=1e-4, atol=1e-2) and torch.equal(s2[:M], s2[M:])
 
 
@@ -182,13 +182,13 @@ def test_gemm_lnx_refusals(hiplib):
     d = hip.GemmDesc(M, C, C, C, C, 0, 0, 1, 0, 1.0, 1, 0)
     parts = hip.gemm_stat_parts(d)
     with pytest.raises(hip.RcdmError):
-        hip.gemm_lnx(d, hip.Lnx(stat.data_ptr(), parts + 1, 0, 0, 0, 1e-5, 0), x.data_ptr(), W.data_ptr(), 0, 0, 0, x.data_ptr(), 0, 0)
+        hip.gemm_lnx(d, hip.Lnx(stat.data_ptr(), parts + 1, M, 0, 0, 0, 0, 1e-5, 0), x.data_ptr(), W.data_ptr(), 0, 0, 0, x.data_ptr(), 0, 0)
     d2 = hip.GemmDesc(M, C, C, C, C, 0, 0, 1, 0, 1.0, 2, 0)
     w = ws(hip.gemm_workspace_bytes(d2))
     with pytest.raises(hip.RcdmError):
-        hip.gemm_lnx(d2, hip.Lnx(0, 0, stat.data_ptr(), parts, S.data_ptr(), 1e-5, C), x.data_ptr(), W.data_ptr(), 0, 0, 0,
+        hip.gemm_lnx(d2, hip.Lnx(0, 0, 0, stat.data_ptr(), parts, M, S.data_ptr(), 1e-5, C), x.data_ptr(), W.data_ptr(), 0, 0, 0,
                      x.data_ptr(), w.data_ptr(), w.numel())
     with pytest.raises(hip.RcdmError):
-        hip.gemm_lnx(d, hip.Lnx(0, 0, stat.data_ptr(), 21, S.data_ptr(), 1e-5, C), x.data_ptr(), W.data_ptr(), 0, 0, 0,
+        hip.gemm_lnx(d, hip.Lnx(0, 0, 0, stat.data_ptr(), 21, M, S.data_ptr(), 1e-5, C), x.data_ptr(), W.data_ptr(), 0, 0, 0,
                      x.data_ptr(), 0, 0)
     torch.cuda.synchronize()

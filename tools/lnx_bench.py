@@ -34,7 +34,7 @@ def main():
         dp = hip.GemmDesc(M, C, C, C, C, C, 1 | 4, 1, 0, 1.0, 0, 0)
         parts = hip.gemm_stat_parts(dp)
         stat = torch.empty(M * max(parts, 1) * 2, dtype=torch.float32, device=DEV)
-        lxp = hip.Lnx(stat.data_ptr(), parts, 0, 0, 0, 1e-5, 0)
+        lxp = hip.Lnx(stat.data_ptr(), parts, M, 0, 0, 0, 0, 1e-5, 0)
         ld = hip.LayerNormDesc(M, C, C, C, 1e-5, 1, 1)
 
         def prod():
@@ -57,7 +57,7 @@ def main():
             plain_epi = (1 | 8) if epi_extra else 0
             dc0 = hip.GemmDesc(M, N, C, C, out.shape[1], 0, plain_epi, 1, 0, 1.0, 0, 0)
             dc1 = hip.GemmDesc(M, N, C, C, out.shape[1], 0, 1 | epi_extra, 1, 0, 1.0, 0, 0)
-            lxc = hip.Lnx(0, 0, stat.data_ptr(), parts, S.data_ptr(), 1e-5, C)
+            lxc = hip.Lnx(0, 0, 0, stat.data_ptr(), parts, M, S.data_ptr(), 1e-5, C)
             w0 = torch.empty(max(hip.gemm_workspace_bytes(dc0), 16), dtype=torch.uint8, device=DEV)
 
             def cons():
