@@ -44,12 +44,13 @@ static inline bool rcdm_first_on_device(bool (&done)[64]) {
 // v_rcp_f32 (1 ulp) instead of an IEEE division: `a / b` and __frcp_rn expand to ~12 VALU ops on gfx950
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact-form (erf) GELU, as diffusers GEGLU.gelu -> F.gelu(approximate="none"): x * Phi(x) with erf by Abramowitz &
-// Stegun 7.1.26 (max |error| of the GELU 3.3e-7 absolute over [-12, 12]: fp32 round-off level, three orders of magnitude
-// below the f16 output rounding; libm erff's ~40 VALU ops made the GEGLU epilogue VALU-bound).  With z = |x| / sqrt(2),
-// t = 1 / (1 + p z), q = (1 - erf(z)) / 2 = poly(t) * exp(-z^2) / 2:   gelu(x) = max(x, 0) - |x| * q
+// Stegun 7.1.25 (three terms, |error of erf| <= 2.5e-5, so |error of the GELU| <= 1.25e-5 |x|: a fortieth of the f16 rounding
+// of the value it is about to be stored as; round 4 — rounds 1-3 used the five-term 7.1.26 at 1.5e-7, two more packed FMAs per
+// pair; libm erff's ~40 VALU ops made the GEGLU epilogue VALU-bound).  With z = |x| / sqrt(2), t = 1 / (1 + p z),
+// q = (1 - erf(z)) / 2 = poly(t) * exp(-z^2) / 2:   gelu(x) = max(x, 0) - |x| * q
 // (sqrt(2) and the 1/2 are folded into the constants).  Written on pairs: v_pk_fma_f32 / v_pk_mul_f32 do two fp32
-// lanes per instruction, so a pair costs 6 packed ops + 2 rcp + 2 exp + 2 max; the epilogues of the K = 320 GEMMs
-// (50 GELUs per thread against 250 MFMAs per wave) are VALU-bound, DESIGN.md section 4a.
+// lanes per instruction, so a pair costs 4 packed ops + 2 rcp + 2 exp + 2 max + 3 mul; the epilogues of the K = 320 GEMMs
+// (50 GELUs per thread against 250 MFMAs per wave) are VALU-bound, DESIGN.md section 4a.  -DRCDM_GELU_5TERM: the old form.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float a) { return f32x2{a, a}; }
 __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
@@ -57,12 +58,19 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
   return f32x2{0.5f * x.x * (1.0f + erff(x.x * 0.70710678118654752f)), 0.5f * x.y * (1.0f + erff(x.y * 0.70710678118654752f))};
 #else
   const f32x2 ax = __builtin_elementwise_abs(x);
+#ifdef RCDM_GELU_5TERM
   const f32x2 d = __builtin_elementwise_fma(ax, splat2(0.2316418882f), splat2(1.0f));  // 0.3275911 / sqrt(2)
   const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-  f32x2 p = __builtin_elementwise_fma(t, splat2(0.5307027145f), splat2(-0.7265760135f));  // A&S coefficients / 2
+  f32x2 p = __builtin_elementwise_fma(t, splat2(0.5307027145f), splat2(-0.7265760135f));  // A&S 7.1.26 coefficients / 2
   p = __builtin_elementwise_fma(p, t, splat2(0.7107068705f));
   p = __builtin_elementwise_fma(p, t, splat2(-0.142248368f));
   p = __builtin_elementwise_fma(p, t, splat2(0.127414796f));
+#else
+  const f32x2 d = __builtin_elementwise_fma(ax, splat2(0.3326725f), splat2(1.0f));  // 0.47047 / sqrt(2)
+  const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  f32x2 p = __builtin_elementwise_fma(t, splat2(0.3739278f), splat2(-0.0479399f));  // A&S 7.1.25 coefficients / 2
+  p = __builtin_elementwise_fma(p, t, splat2(0.1740121f));
+#endif
   const f32x2 xx = x * x * splat2(-0.72134752044f);  // -z^2 * log2(e)
   const f32x2 e = {__builtin_amdgcn_exp2f(xx.x), __builtin_amdgcn_exp2f(xx.y)};
   const f32x2 q = p * t * e;
