@@ -708,6 +708,8 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
         emit_gemm(plan, a.rows(0, Ms), w.qkv1, 3 * C, C, qkv, bias=w.qkv1_b)
     emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), ns, heads, Lq, Lq, d_head, ao.rows(0, Ms))
     chain_q = w.has_cross and w.ch_o1_q is not None and not shared_half and big
+    # (below CHAIN_MIN_ROWS only: with more rows the N = C producers run on the ping-pong kernel, which has no statistics
+    # epilogue — the b = 8 configuration measured 59.5 ms per step without and 60.0 with the deferred form at 40960 rows)
     want_ff = LNX and not big and w.geglu and w.lnx_ff is not None          # statistics for norm3 -> GEGLU
     want_q2 = LNX and not big and w.has_cross and w.lnx_q2 is not None     # statistics for norm2 -> attn2.to_q
     st = None
