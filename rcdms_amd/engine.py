@@ -627,7 +627,40 @@ FF_FUSE = os.environ.get("RCDM_FF_FUSE", "1") != "0"
 ROW_CHAIN = os.environ.get("RCDM_ROWCHAIN", "1") != "0"
 # a chain launch is one block of 160 rows per CU: below ~3/4 of a chip's worth of rows (the 256x256 configuration has
 # 10240 token rows at this width = 64 blocks) the separate tile-parallel launches are faster
-CHAIN_MIN_ROWS = int(os.environ.get("RCDM_CHAIN_MIN_ROWS", str(160 * 192)))
+class _ChainMinRows:
+    """Rows from which the row-stationary chain launches are used: 3/4 of a chip's worth of 160-row blocks, one block per
+    CU — read from the device (hipDeviceAttributeMultiprocessorCount through torch) the first time a plan compares against
+    it, 256 CUs (MI355X: 160 * 192 = 30720 rows) when no device is visible; RCDM_CHAIN_MIN_ROWS overrides."""
+
+    def __init__(self):
+        self._v = None
+
+    def value(self):
+        if self._v is None:
+            env = os.environ.get("RCDM_CHAIN_MIN_ROWS")
+            if env:
+                self._v = int(env)
+            else:
+                cus = 256
+                if torch.cuda.is_available():
+                    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count or 256
+                self._v = 160 * (3 * cus // 4)
+        return self._v
+
+    def __le__(self, other):   # other >= CHAIN_MIN_ROWS
+        return self.value() <= other
+
+    def __gt__(self, other):   # other < CHAIN_MIN_ROWS
+        return self.value() > other
+
+    def __int__(self):
+        return self.value()
+
+    def __repr__(self):
+        return str(self.value())
+
+
+CHAIN_MIN_ROWS = _ChainMinRows()
 CHAIN_PROJ = os.environ.get("RCDM_CHAIN_PROJ", "1") != "0"   # proj_out + residual as the trailing stage of the feed-forward chain
 CHAIN_GN = os.environ.get("RCDM_CHAIN_GN", "1") != "0"   # GroupNorm apply in the prologue of the proj_in chain
 
