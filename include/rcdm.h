@@ -189,6 +189,11 @@ size_t rcdm_groupnorm_workspace_bytes(const rcdm_groupnorm_desc* d);
 int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float* gamma,
                         const float* beta, void* y, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* tuning / test switch: 1 = norms with >= 4 samples and <= 128 partial blocks per sample (the per-frame norms of the
+ * transformers / motion modules) run as TWO launches — statistics, then an apply kernel whose blocks finalise their sample's
+ * groups themselves (bit-identical to the three-launch form) — 0 = always statistics / finalize / apply, -1 = default
+ * (0: the two-launch form measured 0.05 ms per step slower; environment RCDM_GN_FOLD=1 sets 1). */
+int rcdm_set_groupnorm_fold(int32_t on);
 /* statistics only: stat[sample][group][2] = (mean, 1 / sqrt(var + eps)), fp32 — the first two launches of the three-launch
  * form, for a consumer that applies the normalisation itself (rcdm_rowchain's gn_stat: the norm in front of proj_in,
  * attention.py:328-330, motion_module.py:162-166).  ldy / silu of the descriptor are ignored; workspace as above. */

@@ -11,6 +11,7 @@
 namespace {
 
 constexpr int GN_U = 8;  // 16-byte loads a thread of the stats / apply kernels keeps in flight
+int g_gn_fold_mode = -1;
 
 struct GnArgs {
   const f16* x;
@@ -106,22 +107,20 @@ __device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, f
   }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs p) {
-  const int lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (idx >= p.samples * p.G) return;
-  const int s = idx / p.G, g = idx - s * p.G;
+// (mean, rstd) of one (sample, group) from its `splits` partials, by ONE full wave: lanes take the partials lane, lane + 64,
+// ... in order, then a fixed xor-butterfly of Chan's combination.  The arithmetic gn_finalize_kernel has had since round 1
+// (so a fold of this into a consumer is bit-identical to the separate launch); result valid in every lane.
+__device__ __forceinline__ void gn_finalize_group(const float* base, int splits, int lane, float eps, float& mean_out, float& rstd_out) {
   float n = 0.f, mean = 0.f, m2 = 0.f;
   // the (sample, group)'s partials are contiguous: all of a lane's (<= 8) are requested before the first combine, one
   // round trip instead of splits / 64 dependent ones
-  const float* base = p.partial + (size_t)idx * p.splits * 3;
-  for (int sp0 = 0; sp0 < p.splits; sp0 += 512) {
+  for (int sp0 = 0; sp0 < splits; sp0 += 512) {
     float pn[8], pm[8], pq[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int sp = sp0 + lane + 64 * i;
       pn[i] = pm[i] = pq[i] = 0.f;
-      if (sp < p.splits) {
+      if (sp < splits) {
         pn[i] = base[sp * 3];
         pm[i] = base[sp * 3 + 1];
         pq[i] = base[sp * 3 + 2];
@@ -139,18 +138,91 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs p) {
     chan_combine(ln, lm, lq, rn, rm, rq);
     n = ln; mean = lm; m2 = lq;
   }
+  const float var = n > 0.f ? m2 / n : 0.f;  // biased, as torch.nn.GroupNorm
+  mean_out = mean;
+  rstd_out = rsqrtf(var + eps);
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= p.samples * p.G) return;
+  float mean, rstd;
+  gn_finalize_group(p.partial + (size_t)idx * p.splits * 3, p.splits, lane, p.eps, mean, rstd);
   if (lane == 0) {
-    const float var = n > 0.f ? m2 / n : 0.f;  // biased, as torch.nn.GroupNorm
     p.stat[idx * 2] = mean;
-    p.stat[idx * 2 + 1] = rsqrtf(var + p.eps);
+    p.stat[idx * 2 + 1] = rstd;
   }
 }
 
 // grid (blocks_per_sample, samples); same thread->chunk mapping as the stats kernel.
+// FOLD: no gn_finalize launch in front — every block finalises its sample's G groups itself (blockDim is a multiple of 64
+// then: full waves for the butterfly; threads >= CH * RPB only take part in that).  Used where a sample has few partials
+// and many samples share the chip (the per-frame norms of the transformers / motion modules: 10 samples x <= 128 splits),
+// so that a block re-reads <= 50 KB of partials from L2; the cross-frame ResNet norms (2 samples x ~400 splits, ~850 apply
+// blocks) keep the separate launch.
+template <bool FOLD>
 __global__ void gn_apply_kernel(const GnArgs p) {
+  __shared__ float gstat[64 * 2];
   const int t = threadIdx.x;
   const int ch = t % p.CH, rl = t / p.CH;
   const int s = blockIdx.y;
+  if constexpr (FOLD) {
+    // a wave finalises its groups g = wave, wave + nw, ... EIGHT at a time: all their partials (<= 128 splits: two per lane
+    // and group) are requested first, and the eight butterflies run interleaved — one memory round trip and one shuffle
+    // chain per batch instead of one per group.  Per group the same operations in the same order as gn_finalize_group
+    // (a zero partial is an exact no-op of chan_combine).
+    const int lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    for (int g0 = wave; g0 < p.G; g0 += 8 * nw) {
+      float pn[8][2], pm[8][2], pq[8][2];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int g = g0 + k * nw;
+        const float* base = p.partial + ((size_t)s * p.G + min(g, p.G - 1)) * p.splits * 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int sp = lane + 64 * i;
+          const bool ok = g < p.G && sp < p.splits;
+          const float* q = base + (ok ? sp : 0) * 3;
+          const float a = q[0], b = q[1], c = q[2];
+          pn[k][i] = ok ? a : 0.f;
+          pm[k][i] = ok ? b : 0.f;
+          pq[k][i] = ok ? c : 0.f;
+        }
+      }
+      float n[8], mean[8], m2[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        n[k] = mean[k] = m2[k] = 0.f;
+        chan_combine(n[k], mean[k], m2[k], pn[k][0], pm[k][0], pq[k][0]);
+        chan_combine(n[k], mean[k], m2[k], pn[k][1], pm[k][1], pq[k][1]);
+      }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float nb = __shfl_xor(n[k], off, 64), mb = __shfl_xor(mean[k], off, 64), qb = __shfl_xor(m2[k], off, 64);
+          float ln = n[k], lm = mean[k], lq = m2[k], rn = nb, rm = mb, rq = qb;
+          if (lane & off) { ln = nb; lm = mb; lq = qb; rn = n[k]; rm = mean[k]; rq = m2[k]; }
+          chan_combine(ln, lm, lq, rn, rm, rq);
+          n[k] = ln; mean[k] = lm; m2[k] = lq;
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int g = g0 + k * nw;
+          if (g < p.G) {
+            const float var = n[k] > 0.f ? m2[k] / n[k] : 0.f;
+            gstat[g * 2] = mean[k];
+            gstat[g * 2 + 1] = rsqrtf(var + p.eps);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (rl >= p.RPB) return;
+  }
   float sc[8], sh[8];
   {
     const f32x4 g0 = *(const f32x4*)(p.gamma + ch * 8), g1 = *(const f32x4*)(p.gamma + ch * 8 + 4);
@@ -158,7 +230,8 @@ __global__ void gn_apply_kernel(const GnArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int g = (ch * 8 + e) / p.cg;
-      const float mean = p.stat[(s * p.G + g) * 2], rstd = p.stat[(s * p.G + g) * 2 + 1];
+      const float mean = FOLD ? gstat[g * 2] : p.stat[(s * p.G + g) * 2];
+      const float rstd = FOLD ? gstat[g * 2 + 1] : p.stat[(s * p.G + g) * 2 + 1];
       const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
       sc[e] = rstd * ga;
       sh[e] = __builtin_fmaf(-(mean * rstd), ga, be);   // explicit: rowff.hip's prologue form must round the same way
@@ -575,6 +648,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict
 
 extern "C" {
 
+int rcdm_set_groupnorm_fold(int32_t on) {
+  g_gn_fold_mode = on < 0 ? -1 : (on ? 1 : 0);
+  return RCDM_OK;
+}
+
 size_t rcdm_groupnorm_workspace_bytes(const rcdm_groupnorm_desc* d) {
   GnArgs a{};
   if (!d || gn_plan(d, a)) return 0;
@@ -624,15 +702,28 @@ int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.splits, a.samples), dim3(threads), stats_lds, stream, a);
   rc = rcdm_check_launch();
   if (rc) return rc;
-  const int nsg = a.samples * a.G;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, stream, a);
-  rc = rcdm_check_launch();
-  if (rc) return rc;
+  // OFF by default: measured +0.05 ms per step (18.08 -> 18.13 ms, three interleaved pairs on one box) — the ~430 apply blocks
+  // of a 32x32-level per-frame norm each pay a partials round trip + eight butterflies, more than the 4.9 us launch they replace.
+  // RCDM_GN_FOLD=1 / rcdm_set_groupnorm_fold(1) turns it on (bit-identical results).
+  int& fold_mode = g_gn_fold_mode;
+  if (fold_mode < 0) {
+    const char* e = getenv("RCDM_GN_FOLD");
+    fold_mode = e ? atoi(e) : 0;
+  }
+  const int threads64 = (threads + 63) / 64 * 64;
+  const bool fold = fold_mode && a.samples >= 4 && a.splits <= 128 && a.G <= 64 && threads64 <= 1024;
+  if (!fold) {
+    const int nsg = a.samples * a.G;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, stream, a);
+    rc = rcdm_check_launch();
+    if (rc) return rc;
+  }
   int bps = (a.P + a.RPB * 8 - 1) / (a.RPB * 8);  // ~8 rows per thread
   const int cap = (2048 + a.samples - 1) / a.samples;
   if (bps > cap) bps = cap;
   if (bps < 1) bps = 1;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(bps, a.samples), dim3(threads), 0, stream, a);
+  if (fold) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(bps, a.samples), dim3(threads64), 0, stream, a);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(bps, a.samples), dim3(threads), 0, stream, a);
   return rcdm_check_launch();
 }
 

@@ -86,6 +86,7 @@ SYMBOLS = {
     "rcdm_last_hip_error_string": (C.c_char_p, []),
     "rcdm_gemm_ln": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(LnFuse), _P, _P, _P, _P, _P, _P]),
     "rcdm_gemm_stat_parts": (C.c_int, [C.POINTER(GemmDesc)]),
+    "rcdm_set_groupnorm_fold": (C.c_int, [_I]),
     "rcdm_gemm_lnx": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(Lnx), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_gemm_workspace_bytes": (_SZ, [C.POINTER(GemmDesc)]),
     "rcdm_set_igemm_variant": (C.c_int, [_I]),
@@ -244,6 +245,10 @@ def softmax_rows(M, N, ldx, ldy, scale, x, y, stream=None):
 def gemm_ln(desc, ln, a, w, bias, residual, out, stream=None):
     _check(load().rcdm_gemm_ln(C.byref(desc), C.byref(ln), a, w, bias, residual, out,
                                stream_ptr() if stream is None else stream), "rcdm_gemm_ln")
+
+
+def set_groupnorm_fold(on):
+    _check(load().rcdm_set_groupnorm_fold(int(on)), "rcdm_set_groupnorm_fold")
 
 
 def gemm_stat_parts(desc):

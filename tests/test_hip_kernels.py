@@ -373,6 +373,29 @@ def test_groupnorm(hiplib, b, f, H, W, C, cross, silu):
     close(rows_to_5d(y, b, C, f, H, W), ref)
 
 
+@pytest.mark.parametrize("b,f,H,W,C", [(2, 5, 32, 32, 640), (2, 5, 64, 64, 320), (1, 4, 24, 24, 960), (2, 5, 32, 32, 64)])
+def test_groupnorm_fold_is_bit_identical(hiplib, b, f, H, W, C):
+    """Per-frame norms with many samples run as statistics + an apply kernel that finalises the groups itself (round 4); the
+    result must be bit-identical to the three-launch form (same Chan combination in the same order)."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(21 + C)
+    x = h16(torch.randn(b * f * H * W, C, generator=g) * 3.0 + 1.5)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    xd = x.half().to(DEV)
+    d = hip.GroupNormDesc(b * f, H * W, C, 32, C, C, 1e-6, 0)
+    w = ws(hip.groupnorm_workspace_bytes(d))
+    outs = []
+    for mode in (0, 1):
+        hip.set_groupnorm_fold(mode)
+        y = torch.full((b * f * H * W, C), float("nan"), dtype=torch.float16, device=DEV)
+        hip.groupnorm_silu(d, xd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), w.data_ptr(), w.numel())
+        torch.cuda.synchronize()
+        outs.append(y)
+    hip.set_groupnorm_fold(-1)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("M,C,pe", [(50, 320, False), (40, 640, True), (7, 1280, True), (33, 64, False),
                                     # production-sized row counts, ragged last wave
                                     (2051, 320, False), (2400, 320, True), (2049, 640, True), (2050, 1280, False),
