@@ -160,22 +160,21 @@ template <int TPR, int MAXP>
 struct LnxRow {
   static constexpr int NL = (MAXP + TPR - 1) / TPR;
   f32x2 v[NL];
-  // every load is issued unconditionally at a clamped index and zeroed by a select afterwards: a load under a
-  // per-element runtime condition makes hipcc branch around each one and wait for it (NL dependent L2 round trips)
-  // layout: slot-major, stat[slot][ld rows] of (sum, sum of squares) — the lanes of a load instruction (consecutive rows
-  // of one slot) read consecutive 8-byte pairs
+  // layout: slot-major, stat[slot][ld rows] of (sum, sum of squares) — the lanes of a load instruction (consecutive rows of
+  // one slot) read consecutive 8-byte pairs.  Loads go through a buffer descriptor of exactly parts * ld pairs: a slot past
+  // `parts` (and a dead row, sent to offset 2^31) reads as zero in hardware, so there is neither a branch per element (which
+  // hipcc turns into a wait per element) nor a clamp / select / 64-bit address per element — issuing the ten loads of the
+  // first version cost a wave 1270 ticks at kernel start (tools/trace_lnx.py), a buffer load is one VALU add.
   __device__ __forceinline__ void load(const float* stat, int ld, int m, bool live, int parts, int sub) {
-    const f32x2* row = (const f32x2*)stat + (live ? m : 0);
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)stat, 0, parts * ld * 8, 0x00020000);
+    const unsigned stride = (unsigned)(TPR * ld) * 8u;
+    unsigned off = live ? (unsigned)(sub * ld + m) * 8u : 0x80000000u;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      const int idx = sub + j * TPR;
-      v[j] = row[(size_t)min(idx, parts - 1) * ld];
-    }
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const bool ok = live && sub + j * TPR < parts;
-      v[j].x = ok ? v[j].x : 0.f;
-      v[j].y = ok ? v[j].y : 0.f;
+      const u32x2_t r = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+      v[j] = f32x2{__uint_as_float(r.x), __uint_as_float(r.y)};
+      off += stride;
     }
   }
   __device__ __forceinline__ void finish(float invC, float eps, float& rstd, float& mr) const {

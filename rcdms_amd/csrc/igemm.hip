@@ -107,7 +107,11 @@ constexpr int TRACE_SLOTS = 8;
 #else
 #define RCDM_PHASE_BEGIN()
 #define RCDM_PHASE_STAMP(acc_)
+#ifdef RCDM_TRACE_LX   // kernel-start stamps (statistics fetched / first / second barrier) in slots 4-6
+constexpr int TRACE_SLOTS = 8;
+#else
 constexpr int TRACE_SLOTS = 4;
+#endif
 #endif
 
 template <int TAPS, int BM_, int BN_, int WM, int WN, int NSTAGE, bool E16, int LX = 0>  // LX: deferred-LayerNorm epilogues (rcdm_gemm_lnx) compiled in: 1 = row statistics only, 2 = consumer (+ statistics)
@@ -277,6 +281,9 @@ void igemm_dma_kernel(const IgemmArgs p) {
 #endif
     if (t < BN_ / 4 && cn0 + 4 * t < p.N) lx_s4 = *(const f32x4*)(p.lnx_S + cn0 + 4 * t);
   }
+#ifdef RCDM_TRACE_LX
+  if (p.trace) ts_a = __builtin_amdgcn_s_memtime() - ts0;
+#endif
   setup_loader(cm0, cn0);
   const int total = my_tiles * nkl;
   int i_tile = 0, i_ks = 0;   // next (tile, k-step) to issue
@@ -310,12 +317,18 @@ void igemm_dma_kernel(const IgemmArgs p) {
     lx_s4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < BN_ / 4 && n0 + 4 * t < p.N) lx_s4 = *(const f32x4*)(p.lnx_S + n0 + 4 * t);
   };
+#ifdef RCDM_TRACE_LX
+  if (p.trace) ts_b = __builtin_amdgcn_s_memtime() - ts0;
+#endif
 #if !(RCDM_LNX_ABLATE & 1)
   if constexpr (LXC) {
     float r_, m_;
     lx_row0.finish(p.lnx_invC, p.lnx_eps, r_, m_);
     lx_rs = f32x2{r_, m_};
   }
+#endif
+#ifdef RCDM_TRACE_LX
+  if (p.trace) ts_c = __builtin_amdgcn_s_memtime() - ts0 + (long long)(lx_rs.x == 12345.f);   // ticks from kernel start to "statistics finished"
 #endif
   int c_ks = 0, c_tile = 0;   // k-step / tile being computed
   int c_stage = 0;            // ring slot being computed
