@@ -15,6 +15,7 @@ conv3x3 tap-major); cross-attention K/V of the context are computed once per con
 
 torch is used only for device memory, streams and host<->device copies.
 """
+import contextlib
 import math
 import os
 
@@ -67,6 +68,8 @@ class Plan:
         self.tags = []  # one label per op (kind + shape): tools/opprof.py aggregates per-op timings by it
         self.keep = []  # tensors that must outlive the plan (packed weights etc.)
         self.n_launch = 0
+        self._side = None      # second stream: ops emitted inside side_branch() run there (a parallel branch of the step graph)
+        self._in_side = False
 
     def scratch(self, name, nbytes):
         b = self.bufs.get(name)
@@ -98,8 +101,40 @@ class Plan:
     def add(self, fn, tag="misc"):
         if _DROP and tag.split()[0] in _DROP:   # timing experiments only (RCDM_DROP_OPS): the plan computes garbage
             return
+        if self._in_side:
+            side, inner = self._side, fn
+
+            def fn():
+                with torch.cuda.stream(side):
+                    inner()
         self.ops.append(fn)
         self.tags.append(tag)
+
+    @contextlib.contextmanager
+    def side_branch(self):
+        """Ops emitted inside run on the plan's side stream, ordered after everything emitted so far; join_side() orders
+        everything emitted after it behind them.  Captured, the two become a fork and a join of the step graph: an op that
+        nothing needs for a while (a ResNet's 1x1 shortcut) fills the ramps and tails of the launches of the main chain.
+        The side ops must not touch a buffer the main chain writes between the fork and the join.  Without RCDM_FORK=1: in line."""
+        if not FORK:
+            yield
+            return
+        assert not self._in_side
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side, dev = self._side, self.device
+        self.add(lambda: side.wait_stream(torch.cuda.current_stream(dev)), "fork")
+        self._in_side = True
+        try:
+            yield
+        finally:
+            self._in_side = False
+
+    def join_side(self):
+        if not FORK:
+            return
+        side, dev = self._side, self.device
+        self.add(lambda: torch.cuda.current_stream(dev).wait_stream(side), "join")
 
     def run(self, ops=None):
         for op in (self.ops if ops is None else ops):
@@ -137,7 +172,7 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
     d = hip.GemmDesc(A.M, N, K, A.ld, out.ld, residual.ld if residual is not None else 0, epi,
                      rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k, dup_rows)
     wsb = hip.gemm_workspace_bytes(d)
-    ws = plan.scratch("splitk_ws", max(wsb, 256))
+    ws = plan.scratch("splitk_ws_side" if plan._in_side else "splitk_ws", max(wsb, 256))   # (a side branch runs beside the main chain's split-K launches)
     bptr = bias.data_ptr() if bias is not None else 0
     rv_t, rv_off = (rowvec[0], rowvec[1]) if rowvec else (None, 0)
     handle, x = None, None
@@ -277,6 +312,10 @@ LN_FUSE_MAX_N, LN_FUSE_MIN_M = 320, 20480
 # GEMM in front of a LayerNorm emits row statistics, the GEMM behind it takes the raw rows with gamma / beta folded into its
 # weights — no LayerNorm launch, no normalised tensor in HBM.  RCDM_LNX=0 keeps the stand-alone launches (same-process A/B).
 LNX = os.environ.get("RCDM_LNX", "1") != "0"
+# parallel branches in the step graph (Plan.side_branch).  Off: measured +0.03 .. +0.15 ms per step with the fourteen ResNet
+# shortcuts on a side branch (a fork + join of a replayed hipGraph costs more than the ramps and tails the 1x1 GEMM fills,
+# wherever in the block the branch starts; profiles/r4_fork_ab.txt).  RCDM_FORK=1 turns it on (same results, bit for bit).
+FORK = os.environ.get("RCDM_FORK", "0") == "1"
 LNX_MAX_PARTS = 20
 XATTN_MAX_KEYS = 96   # rcdm_xattn: cross-attention with all scores of a query in registers
 
@@ -604,6 +643,11 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
     """ResnetBlock3D.forward (src/models/resnet.py:182-212).  temb = (tensor [b][ldt] fp32, col offset, ldt)
     = this block's slice of the batched time_emb_proj(silu(emb)) table.  x may be a concat view."""
     g = geo
+    res = x
+    if w.shortcut is not None:   # needs only x and is needed only by conv2: a parallel branch of the step graph
+        res = plan.rows("res_sc", g.M, w.cout)
+        with plan.side_branch():
+            emit_gemm(plan, x, w.shortcut, w.cout, w.cin, res, bias=w.sb)
     a1 = plan.rows("norm", g.M, x.C)
     emit_groupnorm(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, True, a1, groups)
     h1 = plan.rows("res_h1", g.M, w.cout)
@@ -611,10 +655,8 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
                  rowvec=(temb[0], temb[1], temb[2], g.f * g.hw))
     a2 = plan.rows("norm", g.M, w.cout)
     emit_groupnorm(plan, h1, g.b, g.f * g.hw, w.g2, w.b2, eps, True, a2, groups)
-    res = x
     if w.shortcut is not None:
-        res = plan.rows("res_sc", g.M, w.cout)
-        emit_gemm(plan, x, w.shortcut, w.cout, w.cin, res, bias=w.sb)
+        plan.join_side()
     emit_conv3x3(plan, a2, g.n_img, g.H, g.W, w.conv2, w.cout, w.cout, out, bias=w.cb2, residual=res, scale=out_scale,
                  dup_rows=dup_rows)
 
