@@ -153,6 +153,9 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
     int c0, tap;
     kpos(ks, c0, tap);
     const int dy = tap / 3, dx = tap - dy * 3;
+#if defined(RCDM_PP_ABLATE) && (RCDM_PP_ABLATE & 8)   // bound of a halo-staged pixel tile: the pixel pieces of 2 taps in 9 only (garbage results)
+    if (TAPS != 1 && tap >= 2) return;
+#endif
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
       const int c = c0 + a_c[i];
