@@ -5,6 +5,7 @@ with procedural name-seeded weights (rcdms_amd/synth.py).  Run in the build cont
     python -m oracle.make_golden [--full] [--only blocks|tiny|ctx|prior|full]   # --full adds the full-width UNet (32x32, 64x64)
     python -m oracle.make_golden --only loop32|loop64|cfg3     # reference-UNet-driven DDIM trajectories / config-3 story
     python -m oracle.make_golden --only eps32|eps64            # reference eps at stored trajectory points x_k (mid / late steps)
+    python -m oracle.make_golden --only skewed                 # full-width UNet with the second ("skewed") weight family, 32x32
 
 What is stored: small inputs and the reference outputs (fp32 .npz), plus a digest of the reference's
 state-dict key/shape list so the mirrored classes are checked to have the identical 1286-key layout.
@@ -34,9 +35,9 @@ def key_digest(sd):
     return h.hexdigest()
 
 
-def load_procedural(module, seed):
+def load_procedural(module, seed, style="unit"):
     sd = module.state_dict()
-    new = synth.procedural_state_dict({k: v.shape for k, v in sd.items()}, seed)
+    new = synth.procedural_state_dict({k: v.shape for k, v in sd.items()}, seed, style)
     module.load_state_dict(new)
     return key_digest(sd)
 
@@ -129,6 +130,27 @@ def full_unet():
         y = m(x, torch.tensor(t), encoder_hidden_states=s["ctx"], return_dict=False)[0]
         print("  reference forward %dx%d: %.1f s" % (hw, hw, time.time() - t0))
         save(f"unet_full_{hw}", t=np.int64(t), y=y, digest=dig)
+
+
+ALT_SEED, ALT_STORY_SEED, ALT_T = 5, 43, 501
+
+
+@torch.no_grad()
+def full_unet_skewed():
+    """The full-width reference UNet with the SECOND weight family (synth style "skewed": per-channel log-normal gains,
+    heavy-tailed entries, wider norm parameters) on another story at a mid-trajectory timestep, 32x32 and 64x64 latents."""
+    t0 = time.time()
+    m = ref_scaffold.build_reference_unet()
+    dig = load_procedural(m, seed=ALT_SEED, style="skewed")
+    print("  full UNet built + skewed weights in %.0f s" % (time.time() - t0))
+    for hw in (32, 64):
+        s = synth.synthetic_story(stories=1, latent_hw=(hw, hw), ctx_len=85, seed=ALT_STORY_SEED)
+        x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1)
+        t0 = time.time()
+        y = m(x, torch.tensor(ALT_T), encoder_hidden_states=s["ctx"], return_dict=False)[0]
+        print("  reference forward %dx%d (skewed weights): %.1f s; |y| rms %.3f max %.3f"
+              % (hw, hw, time.time() - t0, y.pow(2).mean().sqrt(), y.abs().max()))
+        save(f"unet_full_{hw}_skewed", t=np.int64(ALT_T), y=y, digest=dig, seed=np.int64(ALT_SEED), story_seed=np.int64(ALT_STORY_SEED))
 
 
 @torch.no_grad()
@@ -306,6 +328,8 @@ if __name__ == "__main__":
         print("prior transformer"); prior(["prior_tiny"] + (["prior_full"] if a.full else []))
     if a.full or a.only == "full":
         print("full UNet"); full_unet()
+    if a.only == "skewed":
+        print("full UNet, second weight family"); full_unet_skewed()
     if a.only == "pretrained2d":
         print("from_pretrained_2d"); pretrained_2d()
     if a.only == "loop32":

@@ -27,24 +27,39 @@ def sinusoid_table(d_model, max_len):
     return pe
 
 
-def procedural_tensor(name, shape, seed=0):
+def procedural_tensor(name, shape, seed=0, style="unit"):
     """Value of parameter `name`:
       *.pe                         -> the sinusoid table (a buffer, not random)
       norm weights (1-D "*.weight" of a norm) -> 1 + 0.1 N(0,1); 1-D biases -> 0.05 N(0,1)
-      matrices / conv kernels      -> N(0, 1/fan_in)  (unit gain, keeps activations O(1))."""
+      matrices / conv kernels      -> N(0, 1/fan_in)  (unit gain, keeps activations O(1)).
+    style "skewed" — a second weight family for the parity tests, with the features of trained weights the unit-gain
+    family lacks: every matrix row (output channel) and column (input channel) carries its own log-normal gain
+    (sigma 0.5 / 0.35: outlier channels, sharper attention logits), one entry in 512 is 6x larger (heavy tail), norm
+    weights are 1 + 0.3 N(0,1), norm biases 0.2 N(0,1), other biases 0.1 N(0,1)."""
     shape = tuple(int(s) for s in shape)
     if name.endswith("pos_encoder.pe"):
         return sinusoid_table(shape[2], shape[1])
+    if style not in ("unit", "skewed"):
+        raise ValueError(f"unknown weight style {style!r}")
     g = _rng(name, seed)
     x = g.standard_normal(size=shape, dtype=np.float32)
+    skew = style == "skewed"
     if len(shape) == 1:
         if name.endswith(".weight") and _is_norm_param(name):
-            x = 1.0 + 0.1 * x
+            x = 1.0 + (0.3 if skew else 0.1) * x
+        elif skew:
+            x = (0.2 if _is_norm_param(name) else 0.1) * x
         else:
             x = 0.05 * x
     else:
         fan_in = int(np.prod(shape[1:]))
         x = x * (1.0 / math.sqrt(fan_in))
+        if skew:
+            bshape_o = (shape[0],) + (1,) * (len(shape) - 1)
+            bshape_i = (1, shape[1]) + (1,) * (len(shape) - 2)
+            x = x * np.exp(0.5 * g.standard_normal(size=bshape_o, dtype=np.float32))
+            x = x * np.exp(0.35 * g.standard_normal(size=bshape_i, dtype=np.float32))
+            x = np.where(g.random(size=shape, dtype=np.float32) < 1.0 / 512, 6.0 * x, x).astype(np.float32)
     return torch.from_numpy(np.ascontiguousarray(x))
 
 
@@ -62,9 +77,9 @@ def _is_norm_param(name):
     return "norm" in owner
 
 
-def procedural_state_dict(shapes, seed=0):
+def procedural_state_dict(shapes, seed=0, style="unit"):
     """shapes: mapping parameter name -> shape (e.g. from `state_shapes(cfg)` or a module's state_dict)."""
-    return {k: procedural_tensor(k, tuple(v), seed) for k, v in shapes.items()}
+    return {k: procedural_tensor(k, tuple(v), seed, style) for k, v in shapes.items()}
 
 
 def synthetic_story(stories=1, frames=5, latent_hw=(64, 64), ctx_len=85, ctx_dim=768, cfg=True, seed=42):

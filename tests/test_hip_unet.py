@@ -5,6 +5,7 @@ Stated fp16 tolerance (f16 storage between kernels, fp32 accumulation; the refer
 <= 2x what is measured on MI355X so that a regression which doubles the error fails:
   single block        : rel-RMS <= 1.5e-3, max-abs <= 6e-3 * max|ref|     (measured 4-7e-4 / <= 3e-3)
   whole UNet, one call: rel-RMS <= 4e-3,   max-abs <= 6e-3 * max|ref|     (measured 2.0e-3 / 2.4e-3 at full width, 64x64)
+  ... second ("skewed") weight family: rel-RMS <= 7e-3, max-abs <= 1e-2   (measured 3.9e-3 / 5.0e-3)
   same story, different batch: rel-RMS <= 4e-3 (two f16 evaluations with different tile / split-K plans differ by 1.9-2.0e-3)
   sampling loop       : see LOOP_TOL below (measured 8.2e-4 after 20 steps at full width)."""
 import os
@@ -34,11 +35,11 @@ def check(got, ref, rms_tol, max_tol, what=""):
     assert r <= rms_tol and m <= max_tol, f"{what}: rel-RMS {r:.3e} (tol {rms_tol}), max {m:.3e} (tol {max_tol})"
 
 
-def build(kind):
+def build(kind, seed=None, style="unit"):
     """Mirrored class on the GPU with the procedural weights of the fixture."""
     from src.models import attention, motion_module, resnet, unet
     meta = mirrored(kind)
-    sd = synth.procedural_state_dict(shapes_of(meta), SEEDS[kind])
+    sd = synth.procedural_state_dict(shapes_of(meta), SEEDS[kind] if seed is None else seed, style)
     m = meta.to_empty(device="cpu")
     m.load_state_dict(sd)
     return m.to(DEV).eval()
@@ -99,6 +100,26 @@ def test_full_unet_vs_reference(full_unet, hw):
     with torch.no_grad():
         y = full_unet(x, torch.tensor(g["t"]), s["ctx"].to(DEV), return_dict=False)[0]
     check(y, g["y"], 4e-3, 6e-3, f"unet_full_{hw}")
+
+
+def test_full_unet_skewed_weights_vs_reference(hiplib):
+    """A second weight family at full width (every other number is on unit-gain weights): synth style "skewed" —
+    per-channel log-normal gains, 6x outlier entries, wider norm parameters — another story, a mid-trajectory timestep,
+    against the reference UNet's fp32 output with the same weights (oracle/make_golden.py --only skewed).
+    Measured on MI355X: rel-RMS 3.9e-3 (32x32) / 3.7e-3 (64x64), max 5.0e-3 / 3.8e-3 of max|ref| — twice the unit-gain
+    family's 1.9e-3 / 2.0e-3, and the same within 3 % with every fusion switched off (RCDM_LNX=0, RCDM_ATTN_MSUB=0,
+    RCDM_ROWCHAIN=0, RCDM_FF_FUSE=0: profiles/r4_skewed_parity.txt): it is what f16 storage between kernels costs with
+    heavy-tailed weights, not a property of one kernel.  Tolerance (<= 2x measured): rel-RMS 7e-3, max 1e-2."""
+    m = None
+    for hw in (32, 64):
+        g = gold(f"unet_full_{hw}_skewed")
+        if m is None:
+            m = build("unet_full", seed=int(g["seed"]), style="skewed")
+        s = synth.synthetic_story(stories=1, latent_hw=(hw, hw), ctx_len=85, seed=int(g["story_seed"]))
+        x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1).to(DEV)
+        with torch.no_grad():
+            y = m(x, torch.tensor(int(g["t"])), s["ctx"].to(DEV), return_dict=False)[0]
+        check(y, g["y"], 7e-3, 1e-2, f"unet_full_{hw}_skewed")
 
 
 @pytest.mark.parametrize("hw", [32, 64])
