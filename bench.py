@@ -14,7 +14,8 @@ reference's conv/addmm/mm/bmm/baddbmm at b=2,f=5,64x64,L=85) x S / the average r
 events on the launch stream.  The two CFG halves of a step have identical inputs up to the first cross-attention
 (RCDMs_pipeline.py:481-482), so conv_in, the first ResNet block and the first self-attention are evaluated once and
 stored for both (0.21 of the 11.044 TFLOP; exact — config.shared_cfg_prefix, --no-share-prefix for the A/B); `achieved`
-still prices the reference's full 11.044 TFLOP per call (`roofline.flops_skipped_tflop_per_launch` and `achieved_issued` give the issued-work view).  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
+still prices the reference's full 11.044 TFLOP per call (`roofline.flops_skipped_tflop_per_launch` and `achieved_issued` give the issued-work view;
+the second entry of its breakdown is the 5/9 of the three Upsample3D convs that their exact four-phase 2x2 form does not multiply).  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
 timed on this box's host cores on a bounded sample (a few UNet calls of the 50), extrapolated to T calls."""
 import argparse
 import contextlib
@@ -31,6 +32,18 @@ sys.path.insert(0, ROOT)
 ALGO_TFLOP_PER_CALL = {64: 11.044, 32: 2.556}  # per UNet call at b=2 (one story with CFG), L=85  [SURVEY §8d]
 SHARED_PREFIX_TFLOP = {64: 0.208, 32: 0.032}   # per story and call NOT issued under the shared CFG prefix (half of 2 convs 320->320, the first self-attention, 4 C x C / qkv GEMMs)
 MFMA_F16_PEAK_TFLOPS = 2500.0                  # MI355X dense fp16, MI355X_MICROARCH.md
+
+
+def upsample_phase_tflop(plan):
+    """TFLOP per call the plan's phase-form upsampling convs leave out against nearest-2x + conv3x3 (5 of 9 taps)."""
+    import re
+    t = 0.0
+    for tag in plan.tags:
+        m = re.match(r"conv3x3 (\d+)x(\d+)x(\d+) (\d+)->(\d+) s=1 up=2", tag)
+        if m:
+            n, h, w, ci, co = (int(v) for v in m.groups())
+            t += 2.0 * n * 4 * h * w * 5 * ci * co / 1e12
+    return t
 
 
 def init_weights_(model, seed=0):
@@ -316,8 +329,12 @@ def main(argv=None):
         # `achieved` prices the REFERENCE's flops per call; what this build does not issue (the CFG halves' identical prefix,
         # evaluated once) is reported beside it so that the utilisation of the work actually launched can be read off too
         skipped = SHARED_PREFIX_TFLOP.get(a.latent, 0.0) if loop.shared else 0.0
-        roof["flops_skipped_tflop_per_launch"] = round(skipped * S, 4)
-        roof["achieved_issued"] = round(achieved * (1.0 - skipped / (tf_call * (0.5 if a.cfg_split else 1.0))), 1)
+        # ... and the 5/9 of every Upsample3D conv that the phase form (rcdm_conv3x3 upsample = 2) does not multiply: exact
+        # algebra (a nearest-2x upsampled pixel grid holds every source pixel four times), read off the launch plan
+        up2 = upsample_phase_tflop(loop.prog.plan) / S
+        roof["flops_skipped_tflop_per_launch"] = round((skipped + up2) * S, 4)
+        roof["flops_skipped_breakdown"] = {"shared_cfg_prefix": round(skipped * S, 4), "upsample_phase_form": round(up2 * S, 4)}
+        roof["achieved_issued"] = round(achieved * (1.0 - (skipped + up2) / (tf_call * (0.5 if a.cfg_split else 1.0))), 1)
 
     out = {
         "metric": "story-frames/sec (stage-2 UNet, 50-step DDIM, 512^2)", "value": round(value, 4),

@@ -149,11 +149,18 @@ int rcdm_gemm(const rcdm_gemm_desc* d, const void* A, const void* W, const float
  *   in : [n_img*h_in*w_in][lda] f16 (c_in channels used);  W f16 [c_out][9*c_in], k = tap*c_in + c,
  *   tap = ky*3+kx (i.e. torch weight.permute(0,2,3,1)); out rows = n_img*h_out*w_out where
  *   h_out = (h_in*(1+upsample) - 1)/stride + 1.  c_in % 8 == 0, c_out % 8 == 0.
+ *   upsample = 2: the SAME operation as upsample = 1 (Upsample3D: nearest x2, then the 3x3 conv) computed as four 2x2
+ *   "phase" convolutions over the SOURCE grid — output pixel (2y+a, 2x+b) of the upsampled image only ever sees the 2x2
+ *   source pixels (y+a-1+r, x+b-1+c), each with the sum of the 3x3 taps that land on it — 4/9 of the multiply-adds.  W is
+ *   then the phase image written by rcdm_pack_conv3x3_up2 (f16 [4][c_out][4*c_in]: the tap sums are formed in fp32 from the
+ *   fp32 weights and rounded once), the epilogue may only carry RCDM_EPI_BIAS, stride 1, c_in % 64 == 0 (workspace:
+ *   rcdm_conv3x3_workspace_bytes, as for the other forms).  Only shapes whose tiles fill the chip are taken: ask rcdm_conv3x3_up2_supported first (0: use
+ *   upsample = 1 with the [c_out][9*c_in] weights; rcdm_conv3x3 itself returns RCDM_ESHAPE for such a descriptor).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   int32_t n_img, h_in, w_in, c_in, c_out;
   int32_t stride;     /* 1 | 2 */
-  int32_t upsample;   /* 0 | 1 */
+  int32_t upsample;   /* 0 | 1 | 2 (2: phase form of 1, see above) */
   int32_t lda, ldc, ldr;
   int32_t epilogue;
   int32_t rows_per_sample, ldt;
@@ -165,6 +172,7 @@ typedef struct {
 } rcdm_conv3x3_desc;
 
 size_t rcdm_conv3x3_workspace_bytes(const rcdm_conv3x3_desc* d);
+int rcdm_conv3x3_up2_supported(const rcdm_conv3x3_desc* d);   /* 1 | 0, d->upsample == 2 */
 int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, const float* bias,
                  const float* rowvec, const void* residual, void* out, void* workspace,
                  size_t workspace_bytes, void* stream);
@@ -421,6 +429,9 @@ int rcdm_load_table_row(const float* table, const int32_t* step_counter, float* 
  * Weight repacking (fp32 reference layout -> f16 kernel layout), device to device:
  *   rcdm_pack_f16: elementwise fp32 -> f16.
  *   rcdm_pack_conv3x3: torch (Cout,Cin,3,3) fp32 -> f16 [Cout][9*cin_pad], k = tap*cin_pad + c.
+ *   rcdm_pack_conv3x3_up2: torch (Cout,Cin,3,3) fp32 -> f16 [4 phases][Cout][4*Cin] for rcdm_conv3x3 with upsample = 2:
+ *   phase = 2a + b (output parity), k = (2r + c)*Cin + ci, value = sum of w[co][ci][ky][kx] over the taps with
+ *   (a+ky-1)>>1 == a-1+r and (b+kx-1)>>1 == b-1+c.
  *   rcdm_pack_geglu_rows: FeedForward.net.0.proj weight (8C,K)/bias(8C) -> rows reordered so every
  *   32-row group holds 16 "hidden" rows then the matching 16 "gate" rows (RCDM_EPI_GEGLU): the two
  *   land in the same lane of the 16x16x32 and of the 32x32x16 MFMA accumulator layouts.
@@ -428,6 +439,7 @@ int rcdm_load_table_row(const float* table, const int32_t* step_counter, float* 
 int rcdm_pack_f16(const float* src, void* dst, size_t n, void* stream);
 int rcdm_pack_conv3x3(const float* w, int32_t c_out, int32_t c_in, int32_t cin_pad, void* dst,
                       void* stream);
+int rcdm_pack_conv3x3_up2(const float* w, int32_t c_out, int32_t c_in, void* dst, void* stream);
 int rcdm_pack_geglu_rows(const float* w, const float* bias, int32_t n_out /*8C*/, int32_t K,
                          void* w_dst, float* bias_dst, void* stream);
 

@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
         }
       }
     }
-    epilogue_store(p, m, n, v, g);
+    epilogue_store(p, p.ph_rows ? phase_out_row(p, m) : m, n, v, g);   // (phase launches carry a bias at most: no per-row operand)
   }
 }
 
@@ -1104,9 +1104,61 @@ int from_conv(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
   return RCDM_OK;
 }
 
+// upsample = 2: the nearest-2x upsample + conv3x3 as four 2x2 phase convolutions over the source grid (igemm_args.h,
+// IgemmArgs::ph_rows; weights in the rcdm.h phase layout).  4/9 of the flops of the upsample = 1 form.  Runs on the
+// ping-pong kernel only, unsplit: returns the tile shape, or -1 when the shape does not fill the chip that way (the caller
+// keeps the upsample = 1 form — at the 8x8 -> 16x16 level the plain form with split-K is faster).
+int plan_up2(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
+  if (d->upsample != 2 || d->stride != 1 || d->pad_after_only || d->dup_rows) return -1;
+  if (d->epilogue & ~RCDM_EPI_BIAS) return -1;
+  if (d->n_img <= 0 || d->h_in <= 0 || d->w_in <= 0 || d->c_in <= 0 || d->c_out <= 0 || (d->c_in % BK)) return -1;
+  const long long src = (long long)d->n_img * d->h_in * d->w_in;
+  if (4 * src >= 0x7FFFFFFFll || 4ll * d->c_out * 4 * d->c_in * 2 >= 0x7FFFFFFFll) return -1;   // virtual rows are ints; weight offsets 32-bit
+  a.Hi = a.Ho = d->h_in; a.Wi = a.Wo = d->w_in; a.stride = 1; a.up = 0; a.pad = 1;
+  a.ph_rows = (int)src; a.M = 4 * a.ph_rows; a.N = d->c_out; a.Cin = d->c_in; a.Ktot = 4 * d->c_in;
+  a.lda = d->lda; a.ldc = d->ldc; a.ldr = 0; a.ldt = 0; a.rows_per_sample = 1; a.epi = d->epilogue; a.out_scale = d->out_scale;
+  a.dup = 0;
+  const int cus = num_cus();
+  int best = -1;
+  float best_score = 0.70f;
+  const int forced = (g_force_variant >= kFirstPP && g_force_variant < kFirstPP + kNumPPShapes) ? g_force_variant - kFirstPP : -1;
+  for (int sh = 0; sh < kNumPPShapes; ++sh) {
+    const int bm = kPPShapes[sh].bm, bn = kPPShapes[sh].bn;
+    if (a.ph_rows % bm) continue;
+    const int tm = a.M / bm, tn = (a.N + bn - 1) / bn, tiles = tm * tn;
+    if (forced >= 0) {   // rcdm_set_igemm_variant(6 | 7 | 8): that tile shape whatever the fill (tests)
+      if (sh == forced) best = sh;
+      continue;
+    }
+    const int sp = tiles < cus ? pp_splits(tiles, 4 * (a.Cin / BK)) : 1;   // few tiles (the 8x8 -> 16x16 upsampler): cut K like the plain form does
+    const int work = tiles * sp, rounds = (work + cus - 1) / cus;
+    const float score = ((float)a.N / (float)(tn * bn)) * ((float)work / (float)(rounds * cus)) * (sp > 1 ? 0.90f : 1.0f);
+    if (score > best_score) {
+      best_score = score;
+      best = sh;
+    }
+  }
+  if (best < 0) return -1;
+  a.tilesM = a.M / kPPShapes[best].bm;
+  a.tilesN = (a.N + kPPShapes[best].bn - 1) / kPPShapes[best].bn;
+  a.kc = a.Cin / BK;
+  a.nk = 4 * a.kc;
+  int s = d->split_k > 0 ? d->split_k : (a.tilesM * a.tilesN < cus ? pp_splits(a.tilesM * a.tilesN, a.nk) : 1);
+  if (s > a.nk) s = a.nk;
+  a.nk_per_split = (a.nk + s - 1) / s;
+  a.splits = (a.nk + a.nk_per_split - 1) / a.nk_per_split;
+  return best;
+}
+
 }  // namespace
 
 extern "C" {
+
+int rcdm_conv3x3_up2_supported(const rcdm_conv3x3_desc* d) {
+  if (!d) return 0;
+  IgemmArgs a{};
+  return plan_up2(d, a) >= 0 ? 1 : 0;
+}
 
 int rcdm_set_igemm_variant(int32_t v) {
   if (v < -1 || v > 9) return RCDM_EINVAL;
@@ -1215,6 +1267,7 @@ int rcdm_gemm_ln(const rcdm_gemm_desc* d, const rcdm_ln_fuse* ln, const void* A,
 size_t rcdm_conv3x3_workspace_bytes(const rcdm_conv3x3_desc* d) {
   if (!d) return 0;
   IgemmArgs a{};
+  if (d->upsample == 2) return plan_up2(d, a) >= 0 && a.splits > 1 ? (size_t)a.splits * a.M * a.N * sizeof(float) : 0;
   if (from_conv(d, a) || a.Cin <= 0 || a.N <= 0) return 0;
   fill_common(a, d->split_k);
   return a.splits > 1 ? (size_t)a.splits * a.M * a.N * sizeof(float) : 0;
@@ -1224,6 +1277,26 @@ int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, cons
                  const void* residual, void* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!d) return RCDM_EINVAL;
   IgemmArgs a{};
+  if (d->upsample == 2) {
+    const int shape = plan_up2(d, a);
+    if (shape < 0) return RCDM_ESHAPE;
+    if (!in || !W || !out || ((a.epi & RCDM_EPI_BIAS) && !bias)) return RCDM_EINVAL;
+    if ((a.N & 7) || (a.lda & 7) || (a.ldc & 7) || (size_t)a.ph_rows * (size_t)a.lda * 2 >= 0x7FFFFFFFull) return RCDM_ESHAPE;
+    a.A = (const f16*)in; a.W = (const f16*)W; a.bias = bias; a.out = (f16*)out;
+    a.trace = nullptr;
+    a.dbg = 0;
+    if (a.splits > 1) {
+      if (!workspace || workspace_bytes < (size_t)a.splits * a.M * a.N * sizeof(float)) return RCDM_EWORKSPACE;
+      a.partial = (float*)workspace;
+    }
+    int rc = rcdm_igemm_pp_launch(a, 4, shape, (hipStream_t)stream);
+    if (rc || a.splits == 1) return rc;
+    const size_t total = (size_t)a.M * (a.N / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return rcdm_check_launch();
+  }
   int rc = from_conv(d, a);
   if (rc) return rc;
   a.A = (const f16*)in; a.W = (const f16*)W; a.bias = bias; a.rowvec = rowvec;

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
   constexpr unsigned OOB = 0x80000000u;
   const int Hv = p.Hi << p.up, Wv = p.Wi << p.up;
 
+  const int phase = TAPS == 4 ? cm0 / p.ph_rows : 0;   // phase launch (IgemmArgs::ph_rows): the tile's output parity (2a + b)
   // ---- loader state: every group fills the OTHER group's pixel rows; group 0 the lower weight rows, group 1 the upper
   const int myhalf = grp ^ 1, mywhalf = grp;
   const int lrow = lane >> 3, lch = lane & 7;
@@ -111,11 +112,12 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
       if (live && m < p.M) a_off[i] = (unsigned)m * (unsigned)p.lda * 2u;
     } else if (live && m < p.M) {
       const int hw = p.Ho * p.Wo;
-      const int img = m / hw, rem = m - img * hw;
+      const int pm = TAPS == 4 ? m - phase * p.ph_rows : m;   // (phase launch: the source pixel of this virtual row)
+      const int img = pm / hw, rem = pm - img * hw;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
       a_img[i] = img * p.Hi * p.Wi;  // first pixel row of the image
-      a_iy[i] = oy * p.stride - p.pad;
-      a_ix[i] = ox * p.stride - p.pad;
+      a_iy[i] = oy * p.stride - p.pad + (TAPS == 4 ? phase >> 1 : 0);
+      a_ix[i] = ox * p.stride - p.pad + (TAPS == 4 ? phase & 1 : 0);
     }
   }
 #pragma unroll
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
     const int n = cn0 + row;
     w_lds[i] = W_RING + (mywhalf * HN + q * 8) * 128;
     w_c[i] = (lch ^ ((row >> 1) & 7)) * 8;
-    w_off[i] = n < p.N ? (unsigned)n * (unsigned)p.Ktot * 2u : OOB;
+    w_off[i] = n < p.N ? (unsigned)(phase * p.N + n) * (unsigned)p.Ktot * 2u : OOB;
   }
 
   // Every tile of an XCD that shares a weight panel would otherwise stream the SAME weight lines at the same moment
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
   int rot = 0;
   if (p.dbg & 8) {
     const int idx = blockIdx.x >> 3;  // position inside the XCD's run of tiles
-    rot = TAPS == 1 ? idx % nkl : (9 * idx) % nkl;
+    rot = TAPS == 1 ? idx % nkl : (TAPS * idx) % nkl;
   }
   auto kpos = [&](int ks, int& c0, int& tap) __attribute__((always_inline)) {
     ks += rot;
@@ -143,8 +145,8 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
     tap = 0;
     int kci = ks;
     if (TAPS != 1) {  // channel chunk outer, tap inner (the nine windows of one 64-channel slab re-hit L2)
-      kci = ks / 9;
-      tap = ks - kci * 9;
+      kci = ks / TAPS;
+      tap = ks - kci * TAPS;
     }
     c0 = kci * BK;
   };
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
     const int slot = ks & 1;
     int c0, tap;
     kpos(ks, c0, tap);
-    const int dy = tap / 3, dx = tap - dy * 3;
+    const int dy = TAPS == 4 ? tap >> 1 : tap / 3, dx = TAPS == 4 ? tap & 1 : tap - dy * 3;
 #if defined(RCDM_PP_ABLATE) && (RCDM_PP_ABLATE & 8)   // bound of a halo-staged pixel tile: the pixel pieces of 2 taps in 9 only (garbage results)
     if (TAPS != 1 && tap >= 2) return;
 #endif
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
   }
   // every wave is past the last tick: no LDS read and no DMA is outstanding anywhere in the block
 
-  tile_epilogue<FMW, FNW, SLAB, 512, BM, BN, TAPS == 1, TAPS == 1>(p, smem, acc, cm0, cn0, grp * HM, wn * (BN / 4), l15, kg, t);
+  tile_epilogue<FMW, FNW, SLAB, 512, BM, BN, TAPS == 1, TAPS == 1, TAPS == 4>(p, smem, acc, cm0, cn0, grp * HM, wn * (BN / 4), l15, kg, t);
 }
 
 template <int FMW, int FNW>
@@ -398,5 +400,7 @@ int launch_shape(const IgemmArgs& a, int shape, hipStream_t stream) {
 int rcdm_igemm_pp_launch(const IgemmArgs& a, int taps, int shape, hipStream_t stream) {
   if (taps == 1) return launch_shape<1>(a, shape, stream);
   if (taps == 9) return launch_shape<9>(a, shape, stream);
+  if (taps == 4 && shape >= 0 && shape < kNumPPShapes && a.ph_rows > 0 && a.ph_rows % kPPShapes[shape].bm == 0)
+    return launch_shape<4>(a, shape, stream);
   return RCDM_EINVAL;
 }

@@ -45,7 +45,20 @@ struct IgemmArgs {
   const float* lnx_S;
   int lnx_parts, lnx_ld;
   float lnx_invC, lnx_eps;
+  // nearest-2x upsample + conv3x3 as four 2x2 PHASE convolutions over the SOURCE grid (rcdm_conv3x3, upsample = 2; the
+  // ping-pong kernel with TAPS = 4): output pixel (2y + a, 2x + b) sees only the 2x2 source pixels (y + a - 1 + r,
+  // x + b - 1 + c), r, c in {0, 1}, each with the SUM of the 3x3 taps that land on it.  Virtual row m = phase * ph_rows +
+  // source pixel (phase = 2a + b; a tile lies inside one phase: ph_rows % BM == 0); W = [phase][N][4 taps][Cin]; the
+  // epilogue stores virtual row m to output row img * 4HW + (2y + a) * 2W + 2x + b.  0 = not a phase launch.
+  int ph_rows;
 };
+// output row of virtual row m of a phase launch (IgemmArgs::ph_rows): the (2y + a, 2x + b) pixel of the upsampled image
+__device__ __forceinline__ int phase_out_row(const IgemmArgs& p, int m) {
+  const int ph = m / p.ph_rows, pm = m - ph * p.ph_rows;
+  const int hw = p.Hi * p.Wi, img = pm / hw, rem = pm - img * hw;
+  const int y = rem / p.Wi, x = rem - y * p.Wi;
+  return img * 4 * hw + (2 * y + (ph >> 1)) * 2 * p.Wi + 2 * x + (ph & 1);
+}
 constexpr int kLnxMaxParts = 20;   // partial slots per row a consumer can sum (N = 1280 behind 64-wide producer tiles)
 constexpr int kEpiLN = 1 << 20;  // internal epilogue bit (not part of the C-ABI flags)
 
@@ -62,5 +75,6 @@ constexpr int kNumPPShapes = 3;
 extern const PPShape kPPShapes[kNumPPShapes];
 // igemm16.hip: 160x160 tiles, 4 waves, two blocks per CU
 int rcdm_igemm16_launch(const IgemmArgs& a, int taps, hipStream_t stream);
-// taps = 1 | 9; a.tilesM/tilesN/splits/nk_per_split/partial already planned for the shape.  Returns an RCDM_* code.
+// taps = 1 | 9 | 4 (4: the phase form of an upsampling conv, a.ph_rows set); a.tilesM/tilesN/splits/nk_per_split/partial
+// already planned for the shape.  Returns an RCDM_* code.
 int rcdm_igemm_pp_launch(const IgemmArgs& a, int taps, int shape, hipStream_t stream);

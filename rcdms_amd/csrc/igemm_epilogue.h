@@ -13,7 +13,7 @@
 
 __device__ __forceinline__ void epi_store16(f16* dst, uint4 v) { *(uint4*)dst = v; }  // (non-temporal: measured, no change)
 
-template <int FMW, int FNW, bool SLAB, int NT, int BM, int BN, bool LN_OK = false, bool LX = false>  // LX: rcdm_gemm_lnx consumer epilogues compiled in (GEMM launches only)
+template <int FMW, int FNW, bool SLAB, int NT, int BM, int BN, bool LN_OK = false, bool LX = false, bool PH = false>  // LX: rcdm_gemm_lnx consumer epilogues compiled in (GEMM launches only); PH: phase launch (bias-only epilogues, rows remapped)
 __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f32x4 (&acc)[FNW][FMW], int cm0, int cn0,
                                               int row0, int col0, int l15, int kg, int t,
                                               f32x2 lx_pre = f32x2{1.f, 0.f}, bool lx_has_pre = false) {  // lx_pre: thread t's (rstd, mean rstd) of tile row t, summed by the caller
@@ -312,6 +312,10 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
 #if defined(RCDM_I16_ABLATE) && (RCDM_I16_ABLATE & 2)
               if (hh[u].x != 0x7e7e7e7eu) continue;
 #endif
+              if constexpr (PH) {
+                epi_store16(p.out + (size_t)phase_out_row(p, m) * p.ldc + n, hh[u]);
+                continue;
+              }
               epi_store16(p.out + (size_t)m * p.ldc + n, hh[u]);
               if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + n + p.dup) = hh[u];
             }
@@ -406,6 +410,10 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
 #if defined(RCDM_I16_ABLATE) && (RCDM_I16_ABLATE & 2)
             if (o.u.x != 0x7e7e7e7eu) continue;
 #endif
+            if constexpr (PH) {
+              epi_store16(p.out + (size_t)phase_out_row(p, m) * p.ldc + n, o.u);
+              continue;
+            }
             epi_store16(p.out + (size_t)m * p.ldc + n, o.u);
             if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + n + p.dup) = o.u;
           }

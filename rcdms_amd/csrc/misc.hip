@@ -227,6 +227,29 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int c_out, int 
     dst[i] = ci < c_in ? (f16)w[((size_t)co * c_in + ci) * 9 + tap] : (f16)0.f;
   }
 }
+// phase weights of nearest-2x upsample + conv3x3 (rcdm_conv3x3, upsample = 2): dst[phase][co][tap2 * c_in + ci], phase = 2a + b,
+// tap2 = 2r + c = the 2x2 source pixel (y + a - 1 + r, x + b - 1 + c) of output pixel (2y + a, 2x + b); its weight is the
+// fp32 SUM of the 3x3 taps (ky, kx) with (a + ky - 1) >> 1 == a - 1 + r and (b + kx - 1) >> 1 == b - 1 + c:
+// a = 0: r = 0 <- {ky 0}, r = 1 <- {1, 2};   a = 1: r = 0 <- {0, 1}, r = 1 <- {2}   (same for columns)
+__global__ void pack_conv3x3_up2_kernel(const float* __restrict__ w, int c_out, int c_in, f16* __restrict__ dst) {
+  const size_t total = (size_t)4 * c_out * 4 * c_in;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % c_in);
+    size_t q = i / c_in;
+    const int tap2 = (int)(q & 3);
+    q >>= 2;
+    const int co = (int)(q % c_out), phase = (int)(q / c_out);
+    const int a = phase >> 1, b = phase & 1, r = tap2 >> 1, c = tap2 & 1;
+    const float* src = w + ((size_t)co * c_in + ci) * 9;
+    float acc = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      if (((a + ky + 1) >> 1) - 1 != a - 1 + r) continue;   // ((a + ky - 1) >> 1 with the argument kept non-negative)
+      for (int kx = 0; kx < 3; ++kx)
+        if (((b + kx + 1) >> 1) - 1 == b - 1 + c) acc += src[ky * 3 + kx];
+    }
+    dst[i] = (f16)acc;
+  }
+}
 // packed row p: grp = p/32, j = p%32; source row = j<16 ? grp*16+j (hidden) : n_out/2 + grp*16 + (j-16) (gate)
 __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n_out, int K,
                                   f16* __restrict__ wd, float* __restrict__ bd) {
@@ -370,6 +393,13 @@ int rcdm_pack_conv3x3(const float* w, int32_t c_out, int32_t c_in, int32_t cin_p
   const size_t n = (size_t)c_out * 9 * cin_pad;
   hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, c_out, c_in, cin_pad,
                      (f16*)dst);
+  return rcdm_check_launch();
+}
+
+int rcdm_pack_conv3x3_up2(const float* w, int32_t c_out, int32_t c_in, void* dst, void* stream) {
+  if (!w || !dst || c_out <= 0 || c_in <= 0 || (c_in & 7)) return RCDM_EINVAL;
+  const size_t n = (size_t)16 * c_out * c_in;
+  hipLaunchKernelGGL(pack_conv3x3_up2_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, c_out, c_in, (f16*)dst);
   return rcdm_check_launch();
 }
 

@@ -240,6 +240,20 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
     plan.n_launch += 2 if wsb else 1
 
 
+# Upsample3D's nearest-2x + conv3x3 as four 2x2 phase convolutions over the source grid (rcdm_conv3x3 upsample = 2: 4/9 of
+# the multiply-adds) wherever the library takes the shape; RCDM_UP2=0 keeps the upsample = 1 form (same-process A/B)
+UP2 = os.environ.get("RCDM_UP2", "1") != "0"
+
+
+def emit_upsample_conv(plan, pk, wkey, x, n_img, H, W, c, out, bias):
+    """Upsample3D.forward (src/models/resnet.py:60-79): F.interpolate(scale 2, nearest) + conv3x3, c -> c channels."""
+    d2 = hip.ConvDesc(n_img, H, W, c, c, 1, 2, x.ld, out.ld, 0, hip.EPI_BIAS if bias is not None else 0, 1, 0, 1.0, 0, 0, 0)
+    if UP2 and hip.conv3x3_up2_supported(d2):
+        emit_conv3x3(plan, x, n_img, H, W, pk.conv3x3_up2(wkey), c, c, out, up=2, bias=bias)
+    else:
+        emit_conv3x3(plan, x, n_img, H, W, pk.conv3x3(wkey), c, c, out, up=1, bias=bias)
+
+
 def emit_groupnorm(plan, x, samples, rows_per_sample, gamma, beta, eps, silu, out, groups=32):
     d = hip.GroupNormDesc(samples, rows_per_sample, x.C, groups, x.ld, out.ld, eps, int(silu))
     ws = plan.scratch("gn_ws", hip.groupnorm_workspace_bytes(d))
@@ -397,6 +411,15 @@ class Packer:
             cout = cout_pad
         dst = torch.empty(cout, 9 * cin_pad, dtype=torch.float16, device=self.device)
         hip.pack_conv3x3(w.data_ptr(), cout, cin, cin_pad, dst.data_ptr())
+        self._tmp.append(w)
+        return dst
+
+    def conv3x3_up2(self, key):
+        """Phase weights of an Upsample3D conv (rcdm_conv3x3 with upsample = 2): f16 [4][cout][4 * cin]."""
+        w = self.f32(key)
+        cout, cin = w.shape[0], w.shape[1]
+        dst = torch.empty(4, cout, 4 * cin, dtype=torch.float16, device=self.device)
+        hip.pack_conv3x3_up2(w.data_ptr(), cout, cin, dst.data_ptr())
         self._tmp.append(w)
         return dst
 
@@ -1131,9 +1154,8 @@ class UNetProgram:
                 cur = layer(pb, j, kind == "CrossAttnUpBlock3D", 2 ** (nlev - 1 - i), x, geo, dst)
                 k -= 1
             if not last_block:
-                usw = pk.conv3x3(pb + "upsamplers.0.conv.weight")
-                emit_conv3x3(plan, cur, geo.n_img, geo.H, geo.W, usw, rev[i], rev[i], h_view(k), up=1,
-                             bias=pk.vec(pb + "upsamplers.0.conv.bias"))
+                emit_upsample_conv(plan, pk, pb + "upsamplers.0.conv.weight", cur, geo.n_img, geo.H, geo.W, rev[i], h_view(k),
+                                   pk.vec(pb + "upsamplers.0.conv.bias"))
         assert k == -1
 
         # ---- output head (unet.py:455-457) -------------------------------------------------------------

@@ -131,6 +131,8 @@ SYMBOLS = {
     "rcdm_pack_f16": (C.c_int, [_P, _P, _SZ, _P]),
     "rcdm_mish": (C.c_int, [_P, _P, _SZ, _P]),
     "rcdm_pack_conv3x3": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "rcdm_pack_conv3x3_up2": (C.c_int, [_P, _I, _I, _P, _P]),
+    "rcdm_conv3x3_up2_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "rcdm_pack_geglu_rows": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
     "rcdm_graph_begin_capture": (C.c_int, [_P]),
     "rcdm_graph_end_capture": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
@@ -389,6 +391,15 @@ def pack_f16(src, dst, n, stream=None):
 
 def mish(x, y, n, stream=None):
     _check(load().rcdm_mish(x, y, n, stream_ptr() if stream is None else stream), "rcdm_mish")
+
+
+def pack_conv3x3_up2(w, c_out, c_in, dst, stream=None):
+    _check(load().rcdm_pack_conv3x3_up2(w, c_out, c_in, dst, stream_ptr() if stream is None else stream),
+           "rcdm_pack_conv3x3_up2")
+
+
+def conv3x3_up2_supported(desc):
+    return bool(load().rcdm_conv3x3_up2_supported(C.byref(desc)))
 
 
 def pack_conv3x3(w, c_out, c_in, cin_pad, dst, stream=None):

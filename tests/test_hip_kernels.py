@@ -334,6 +334,77 @@ def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split, variant):
     close(rows_to_5d(out, b, cout, f, Ho, Wo), ref)
 
 
+@pytest.mark.parametrize("n_img,H,W,cin,cout,variant,split", [
+    (5, 16, 16, 64, 96, 6, 0),       # 1280 source pixels = 8 tiles of 160 rows per phase; N tail (96 of a 320-wide tile)
+    (5, 16, 16, 128, 256, 7, 0),     # 160x256 tiles
+    (5, 16, 16, 64, 520, 8, 0),      # 256x256 tiles, three column tiles, the last one 8 columns wide
+    (10, 8, 8, 192, 64, 6, 0),       # 8x8 images: 2.5 images per 160-row tile (image borders inside a tile)
+    (10, 8, 8, 192, 64, 6, 3),       # ... split-K: fp32 slabs + the reduce pass store the remapped rows
+    (10, 16, 16, 1280, 1280, -1, 0), # the 16x16 -> 32x32 upsampler of the UNet, heuristic tile
+    (10, 8, 8, 1280, 1280, -1, 0),   # the 8x8 -> 16x16 upsampler: 64 tiles, heuristic split-K
+])
+def test_conv3x3_upsample_phase_form(hiplib, n_img, H, W, cin, cout, variant, split):
+    """rcdm_conv3x3 with upsample = 2 (four 2x2 phase convolutions over the source grid, weights from
+    rcdm_pack_conv3x3_up2) against nearest-2x upsample + conv3x3 in fp32 (resnet.py:60-79), and against the library's own
+    upsample = 1 form on the same operands."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(500 + cin + cout + H)
+    x = h16(torch.randn(1, cin, n_img, H, W, generator=g))
+    w = h16(torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=g)
+    ref = O.conv_frames(F.interpolate(x, scale_factor=[1.0, 2.0, 2.0], mode="nearest"), w, bias, stride=1, padding=1)
+    lda = cin + 8
+    xd = rows_from_5d(x, lda)
+    w32, bd = w.to(DEV), bias.to(DEV)
+    wp2 = torch.empty(4, cout, 4 * cin, dtype=torch.float16, device=DEV)
+    hip.pack_conv3x3_up2(w32.data_ptr(), cout, cin, wp2.data_ptr())
+    # the packed image against the definition: phase (a, b), source tap (r, c) = sum of the 3x3 taps that land on it
+    rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+    for a in (0, 1):
+        for b in (0, 1):
+            for r in (0, 1):
+                for c in (0, 1):
+                    want = w[:, :, rows[a][r]][:, :, :, rows[b][c]].sum(dim=(2, 3))
+                    got = wp2[2 * a + b].view(cout, 4, cin)[:, 2 * r + c].float().cpu()
+                    assert (got - want).abs().max() <= 1e-3 * want.abs().max() + 1e-6
+    out = torch.full((n_img * 4 * H * W, cout), float("nan"), dtype=torch.float16, device=DEV)
+    d2 = hip.ConvDesc(n_img, H, W, cin, cout, 1, 2, lda, cout, 0, hip.EPI_BIAS, 1, 0, 1.0, split)
+    hip.set_igemm_variant(variant)
+    try:
+        assert hip.conv3x3_up2_supported(d2)
+        w2 = ws(hip.conv3x3_workspace_bytes(d2))
+        assert (hip.conv3x3_workspace_bytes(d2) > 0) == (split > 1 or (n_img, H, cin) == (10, 8, 1280))
+        hip.conv3x3(d2, xd.data_ptr(), wp2.data_ptr(), bd.data_ptr(), 0, 0, out.data_ptr(), w2.data_ptr(), w2.numel())
+        torch.cuda.synchronize()
+    finally:
+        hip.set_igemm_variant(-1)
+    close(rows_to_5d(out, 1, cout, n_img, 2 * H, 2 * W), ref)
+    wp = torch.empty(cout, 9 * cin, dtype=torch.float16, device=DEV)
+    hip.pack_conv3x3(w32.data_ptr(), cout, cin, cin, wp.data_ptr())
+    out1 = torch.empty_like(out)
+    d1 = hip.ConvDesc(n_img, H, W, cin, cout, 1, 1, lda, cout, 0, hip.EPI_BIAS, 1, 0, 1.0, 0)
+    wsb = ws(hip.conv3x3_workspace_bytes(d1))
+    hip.conv3x3(d1, xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), 0, 0, out1.data_ptr(), wsb.data_ptr(), wsb.numel())
+    torch.cuda.synchronize()
+    diff = (out.float() - out1.float()).abs().max().item()
+    assert diff <= 4e-3 * ref.abs().max().item(), diff
+
+
+def test_conv3x3_upsample_phase_form_refusals(hiplib):
+    """Shapes and epilogues the phase form does not take are refused by rcdm_conv3x3 and reported by the query."""
+    from rcdms_amd import hip
+    ok = hip.ConvDesc(10, 16, 16, 1280, 1280, 1, 2, 1280, 1280, 0, hip.EPI_BIAS, 1, 0, 1.0, 0)
+    assert hip.conv3x3_up2_supported(ok)
+    for bad in (hip.ConvDesc(10, 16, 16, 1280, 1280, 1, 2, 1280, 1280, 1280, hip.EPI_BIAS | hip.EPI_RESIDUAL, 1, 0, 1.0, 0),
+                hip.ConvDesc(10, 16, 16, 1272, 1280, 1, 2, 1272, 1280, 0, hip.EPI_BIAS, 1, 0, 1.0, 0),     # c_in % 64
+                hip.ConvDesc(1, 8, 8, 64, 64, 1, 2, 64, 64, 0, hip.EPI_BIAS, 1, 0, 1.0, 0),                # does not fill the chip
+                hip.ConvDesc(10, 16, 16, 1280, 1280, 2, 2, 1280, 1280, 0, hip.EPI_BIAS, 1, 0, 1.0, 0)):    # stride 2
+        assert not hip.conv3x3_up2_supported(bad)
+        x = torch.zeros(16, dtype=torch.float16, device=DEV)
+        with pytest.raises(hip.RcdmError):
+            hip.conv3x3(bad, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, x.data_ptr(), x.data_ptr(), 0, 0)
+
+
 @pytest.mark.parametrize("b,f,H,W,C,cross,silu", [
     (2, 5, 8, 8, 320, True, True),      # resnet norm: statistics across the 5 frames
     (2, 5, 8, 8, 320, False, False),    # transformer / motion-module norm: per frame, eps 1e-6
