@@ -18,7 +18,8 @@ import torch
 from torch import nn
 
 from . import hip
-from .engine import (CIN_PAD, COUT_PAD, Geo, Packer, Plan, Rows, _NS, emit_conv3x3, emit_gemm, emit_groupnorm)
+from .engine import (CIN_PAD, COUT_PAD, Geo, Packer, Plan, Rows, _NS, emit_conv3x3, emit_gemm, emit_groupnorm,
+                     emit_upsample_conv)
 
 SD15_VAE = dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, out_channels=3,
                 in_channels=3, norm_num_groups=32, scaling_factor=0.18215)
@@ -260,7 +261,7 @@ class VaeDecodeProgram:
                 out = plan.rows(f"vae_s{idx}", up.M, c, unique=True)
                 idx += 1
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv."
-                emit_conv3x3(plan, cur, n, geo.H, geo.W, pk.conv3x3(p + "weight"), c, c, out, up=1, bias=pk.vec(p + "bias"))
+                emit_upsample_conv(plan, pk, p + "weight", cur, n, geo.H, geo.W, c, out, pk.vec(p + "bias"))
                 cur, geo = out, up
         a = plan.rows("norm", geo.M, rev[-1])
         emit_groupnorm(plan, cur, n, geo.hw, pk.vec("decoder.conv_norm_out.weight"), pk.vec("decoder.conv_norm_out.bias"),
