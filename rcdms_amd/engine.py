@@ -326,6 +326,10 @@ LN_FUSE_MAX_N, LN_FUSE_MIN_M = 320, 20480
 # GEMM in front of a LayerNorm emits row statistics, the GEMM behind it takes the raw rows with gamma / beta folded into its
 # weights — no LayerNorm launch, no normalised tensor in HBM.  RCDM_LNX=0 keeps the stand-alone launches (same-process A/B).
 LNX = os.environ.get("RCDM_LNX", "1") != "0"
+# proj_out folded into the feed-forward's second GEMM below the chain kernels' row count (Packer.ffz): the token rows live in
+# the last C columns of a [M][5C] buffer whose first 4C columns the GEGLU projection fills, so one K = 5C GEMM replaces
+# ff.net.2 (+ residual) and proj_out (+ residual).  RCDM_FFZ=0: the two GEMMs (same-process A/B)
+FFZ = os.environ.get("RCDM_FFZ", "1") != "0"
 # parallel branches in the step graph (Plan.side_branch).  Off: measured +0.03 .. +0.15 ms per step with the fourteen ResNet
 # shortcuts on a side branch (a fork + join of a replayed hipGraph costs more than the ramps and tails the 1x1 GEMM fills,
 # wherever in the block the branch starts; profiles/r4_fork_ab.txt).  RCDM_FORK=1 turns it on (same results, bit for bit).
@@ -413,6 +417,23 @@ class Packer:
         hip.pack_conv3x3(w.data_ptr(), cout, cin, cin_pad, dst.data_ptr())
         self._tmp.append(w)
         return dst
+
+    def ffz(self, ff2_key, ff2_bkey, po_key, po_bkey):
+        """proj_out behind the feed-forward's second Linear as ONE matrix over [h | tok] (two linear maps in a row, no
+        nonlinearity between: attention.py:514 + :361, motion_module.py:243 + :178):
+            proj_out(tok + ff2 h + b2) + b_po = [W_po W_ff2 | W_po] [h | tok]^T + (W_po b2 + b_po)
+        -> (f16 [C][5C], fp32 [C]); the products are formed in fp32 and rounded once.  None when FFZ is off."""
+        if not FFZ:
+            return None
+        w2, b2 = self.f32(ff2_key), self.f32(ff2_bkey)
+        wpo = self.f32(po_key)
+        wpo = wpo.reshape(wpo.shape[0], -1)
+        bpo = self.f32(po_bkey)
+        src = torch.cat([wpo @ w2, wpo], dim=1).contiguous()
+        dst = torch.empty(src.shape, dtype=torch.float16, device=self.device)
+        hip.pack_f16(src.data_ptr(), dst.data_ptr(), src.numel())
+        self._tmp.append(src)
+        return _NS(W=dst, b=(wpo @ b2 + bpo).contiguous())
 
     def conv3x3_up2(self, key):
         """Phase weights of an Upsample3D conv (rcdm_conv3x3 with upsample = 2): f16 [4][cout][4 * cin]."""
@@ -598,6 +619,10 @@ def pack_transformer(pk, p):
     w.gn_g, w.gn_b = pk.vec(p + "norm.weight"), pk.vec(p + "norm.bias")
     w.proj_in, w.proj_in_b = pk.mat_f16(p + "proj_in.weight"), pk.vec(p + "proj_in.bias")
     w.proj_out, w.proj_out_b = pk.mat_f16(p + "proj_out.weight"), pk.vec(p + "proj_out.bias")
+    w.ffz = None
+    if w.geglu:
+        t = p + "transformer_blocks.0."
+        w.ffz = pk.ffz(t + "ff.net.2.weight", t + "ff.net.2.bias", p + "proj_out.weight", p + "proj_out.bias")
     # ... and the block's last chain with proj_out + the transformer's residual behind the feed-forward
     w.ch_o2_ffz = None
     if CHAIN_PROJ and w.ch_o2_ff is not None:
@@ -632,6 +657,7 @@ def pack_motion(pk, p, n_attn):
     w.ff1, w.ff1_b = pk.geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias")
     w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
     w.ff_stream = pk.ff_stream(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight")
+    w.ffz = pk.ffz(b + "ff.net.2.weight", b + "ff.net.2.bias", p + "proj_out.weight", p + "proj_out.bias")
     # row-stationary chains: proj_in -> norms[0] + pe -> qkv;  to_out + res -> norms[1] + pe -> qkv;  to_out + res ->
     # ff_norm -> ff -> + res
     w.chains = w.chain_ffz = None
@@ -753,11 +779,24 @@ def emit_rowchain(plan, a_in, res, tok, a_bias, ln, pe, stream, tail, out, rows_
     plan.last_gemm = None
 
 
-def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None, tok_stat=None, lnx=None):
+def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None, tok_stat=None, lnx=None, z=None):
     """x += FeedForward_geglu(LayerNorm(x))  (attention.py:514 / motion_module.py:243), in place on tok.
     stream: (fragment-major weight stream, packed b1) of Packer.ff_stream, or None for the unfused chain.
     tok_stat / lnx: row statistics of tok from the GEMM that wrote it + Packer.lnx_geglu operands — the LayerNorm then
-    rides in the GEGLU projection's epilogue (deferred LayerNorm)."""
+    rides in the GEGLU projection's epilogue (deferred LayerNorm).
+    z = (ffz, cat, x, out): tok is the last C columns of cat [M][5C] (ffz_rows); the feed-forward's own result is not
+    stored — out = x + proj_out(tok + FF(..)) comes out of ONE K = 5C GEMM over [h | tok] (Packer.ffz)."""
+    if z is not None:
+        ffz, cat, x, out = z
+        gg = cat.cols(0, 4 * C)
+        assert tok.ptr_key() == cat.cols(4 * C, C).ptr_key() and M < CHAIN_MIN_ROWS
+        if tok_stat is not None and lnx is not None and gemm_lnx_ok(M, 8 * C, C, tok.ld, gg.ld, geglu=True):
+            emit_gemm(plan, tok, lnx.W, 8 * C, C, gg, bias=lnx.b, geglu=True, lnx=(tok_stat, lnx.S))
+        else:
+            emit_layernorm(plan, tok, ln_g, ln_b, a)
+            emit_gemm(plan, a, ff1, 8 * C, C, gg, bias=ff1_b, geglu=True)
+        emit_gemm(plan, cat, ffz.W, C, 5 * C, out, bias=ffz.b, residual=x)
+        return
     if stream is not None and M >= CHAIN_MIN_ROWS:
         ws, b1p = stream
         d = hip.FFDesc(M, C, tok.ld, tok.ld, 1e-5)
@@ -779,7 +818,7 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None,
 
 
 def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False, ctx_img=None, pre=None, post=None,
-                     tok_stat=None):
+                     tok_stat=None, z=None):
     """BasicTransformerBlock.forward (src/models/attention.py:479-526) in place on tok [n_seq*Lq][C]:
     h += attn1(LN1(h)); h += attn2(LN2(h), ctx); h += FF(LN3(h)).  ctx_kv: Rows [n_seq*L][2C] = [K | V] of the context.
     shared_half: the two halves of tok (the CFG halves of a denoising step) hold IDENTICAL rows on entry — everything up
@@ -838,12 +877,22 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
         st = emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok, stat=want_ff)
     if w.geglu:
         emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, M, C, stream=w.ff_stream,
-                tok_stat=st if st is not None and st.M >= M else None, lnx=w.lnx_ff)
+                tok_stat=st if st is not None and st.M >= M else None, lnx=w.lnx_ff, z=z)
     else:   # FeedForward("gelu"): Linear -> exact GELU -> Linear (stage-1 prior blocks)
         emit_layernorm(plan, tok, w.ln[2][0], w.ln[2][1], a)
         hid = plan.rows("geglu", M, 4 * C)
         emit_gemm(plan, a, w.ff1, 4 * C, C, hid, bias=w.ff1_b, gelu=True)
         emit_gemm(plan, hid, w.ff2, C, 4 * C, tok, bias=w.ff2_b, residual=tok)
+
+
+def ffz_rows(plan, w, M, C, x, out):
+    """(z, tok) for a transformer / motion module: below the chain kernels' row count, with a GEGLU feed-forward and
+    Packer.ffz operands, the token rows are the last C columns of a [M][5C] buffer and z = (ffz, cat, x, out) tells emit_ff
+    to fold proj_out (+ the module's residual x) into the feed-forward's second GEMM; else (None, plain token rows)."""
+    if getattr(w, "ffz", None) is not None and M < CHAIN_MIN_ROWS:
+        cat = plan.rows("ffcat", M, 5 * C)
+        return (w.ffz, cat, x, out), cat.cols(4 * C, C)
+    return None, plan.rows("tok", M, C)
 
 
 def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_half=False, ctx_img=None):
@@ -853,7 +902,7 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     g, C = geo, w.C
     n_s, M_s = (g.n_img // 2, g.M // 2) if shared_half else (g.n_img, g.M)
     a = plan.rows("norm", g.M, C)
-    tok = plan.rows("tok", g.M, C)
+    z, tok = ffz_rows(plan, w, g.M, C, x, out)
     pre, tok_stat = None, None
     if w.ch_in_qkv is not None and not shared_half and g.M >= CHAIN_MIN_ROWS:
         if CHAIN_GN and g.hw % 16 == 0 and g.hw >= 160:   # the norm's apply rides too: only its statistics are launched
@@ -868,8 +917,8 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     post = (w.ch_o2_ffz, x, w.proj_out_b, out) if (getattr(w, "ch_o2_ffz", None) is not None and w.has_cross and
                                                    g.M >= CHAIN_MIN_ROWS) else None
     emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img, pre=pre,
-                     post=post, tok_stat=tok_stat)
-    if post is None:
+                     post=post, tok_stat=tok_stat, z=z)
+    if post is None and z is None:
         emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
 
 
@@ -898,7 +947,7 @@ def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
         gn = emit_groupnorm_stats(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, groups)
     else:
         emit_groupnorm(plan, x, g.n_img, g.hw, w.gn_g, w.gn_b, 1e-6, False, a, groups)
-    tok = plan.rows("tok", g.M, C)
+    z, tok = (None, plan.rows("tok", g.M, C)) if chained else ffz_rows(plan, w, g.M, C, x, out)
     if chained:
         # three chain launches + two temporal attentions + proj_out instead of twelve launches
         qkv = plan.rows("qkv", g.M, 3 * C)
@@ -933,8 +982,9 @@ def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
         emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)
         st = emit_gemm(plan, ao, at.o, C, C, tok, bias=at.o_b, residual=tok, stat=want_stat)
     emit_ff(plan, tok, w.ff_ln[0], w.ff_ln[1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, g.M, C, stream=w.ff_stream, tok_stat=st,
-            lnx=w.lnx_ff)
-    emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
+            lnx=w.lnx_ff, z=z)
+    if z is None:
+        emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
 
 
 # ------------------------------------------------------------------------------------------------
