@@ -24,6 +24,7 @@
 //     16-byte-per-lane epilogue (bias / per-sample row vector / GELU / GEGLU / residual / scale in fp32) while the
 //     other stage already receives the next tile.
 //   tiles <BM, BN, WM x WN waves>: 128x128 (2x2, two blocks per CU) and 256x256 (2x4, one block per CU).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
@@ -844,6 +845,64 @@ bool pick_16(const IgemmArgs& a) {
   return a.M >= 5120 && a.M < 20480 && a.N >= 640 && a.N <= 1280;
 }
 
+// Per-shape overrides of the heuristics below: {taps, M, N, C_in} -> tile variant (1 .. 9) and split-K factor (0 = that
+// variant's own heuristic).  kShapeRules holds what tools/autotune.py found AND a same-box A/B of the whole step
+// confirmed; RCDM_SHAPE_RULES="taps,M,N,Cin,variant,split;..." adds rules at run time (first match wins: the environment's
+// rules are looked at first), RCDM_SHAPE_RULES=off ignores the table — for tuning another chip or another model without
+// a rebuild.  A rule is skipped where its variant cannot run the launch (row statistics: variants 1 .. 5; deferred-
+// LayerNorm consumers: not the ping-pong kernel).
+struct ShapeRule { int taps, M, N, Cin, variant, split; };
+const ShapeRule kShapeRules[] = {
+    // the headline workload (b = 2 x 5 frames, 64x64 latents), round 4: profiles/r4_autotune.txt, profiles/r4_shape_rules_ab.txt
+    {9, 40960, 320, 320, kVar16, 1},   // the convs of the 64x64 level on 160x160 tiles, two blocks per CU, instead of the
+    {9, 40960, 320, 640, kVar16, 1},   //   160x320 ping-pong tile (-3 % back to back, -0.15 ms per step together in the graph)
+    {9, 40960, 320, 960, kVar16, 1},
+    {9, 20480, 320, 320, kVar16, 0},   // ... and of the shared-prefix half batch
+    {1, 640, 1280, 2560, 3, 3},        // 1x1 shortcuts of the 8x8 / 16x16 up blocks: 64x64 tiles split 3 ways / 128x64 tiles
+    {1, 2560, 1280, 2560, 5, 0},
+    {0, 0, 0, 0, 0, 0},   // (terminator)
+};
+const ShapeRule* find_shape_rule(const IgemmArgs& a) {
+  static ShapeRule env_rules[32];
+  static int n_env = -1;
+  static bool table_on = true;
+  if (n_env < 0) {
+    int n = 0;
+    const char* e = getenv("RCDM_SHAPE_RULES");
+    if (e && !strcmp(e, "off")) {
+      table_on = false;
+    } else if (e) {
+      while (*e && n < 32) {
+        ShapeRule r{};
+        int used = 0;
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d%n", &r.taps, &r.M, &r.N, &r.Cin, &r.variant, &r.split, &used) == 6 && r.variant >= 1 &&
+            r.variant <= 9 && r.split >= 0)
+          env_rules[n++] = r;
+        e += used;
+        while (*e && *e != ';') ++e;
+        if (*e == ';') ++e;
+        if (!used) break;
+      }
+    }
+    n_env = n;
+  }
+  if (a.ph_rows) return nullptr;
+  const int taps = a.Ktot / a.Cin;
+  auto fits = [&](const ShapeRule& r) {
+    if (r.taps != taps || r.M != a.M || r.N != a.N || r.Cin != a.Cin) return false;
+    if (a.stat_out && r.variant > 5) return false;
+    if (a.lnx_stat && r.variant >= kFirstPP && r.variant < kVar16) return false;
+    if ((a.stat_out || a.lnx_stat) && r.split > 1) return false;
+    return true;
+  };
+  for (int i = 0; i < n_env; ++i)
+    if (fits(env_rules[i])) return &env_rules[i];
+  if (table_on)
+    for (const ShapeRule* r = kShapeRules; r->variant; ++r)
+      if (fits(*r)) return r;
+  return nullptr;
+}
+
 int pick_variant(const IgemmArgs& a) {
   if (g_force_variant < 0) {
     const char* e = getenv("RCDM_IGEMM");
@@ -853,6 +912,7 @@ int pick_variant(const IgemmArgs& a) {
     if (e && !strcmp(e, "dma64")) g_force_variant = 3;
   }
   if (g_force_variant != 99) return g_force_variant == 0 ? 1 : g_force_variant;
+  if (const ShapeRule* r = find_shape_rule(a)) return r->variant;
   if (g_pp_mode < 0) {
     const char* e = getenv("RCDM_PP");
     g_pp_mode = e ? atoi(e) : 1;
@@ -912,7 +972,10 @@ int fill_common(IgemmArgs& a, int requested_split, int* variant_out = nullptr) {
   const int taps = a.Ktot / a.Cin;
   a.nk = taps * a.kc;
   int s;
-  if (variant >= kFirstPP && variant < kVar16 && requested_split <= 0) {
+  const ShapeRule* rule = (g_force_variant == 99 && requested_split <= 0) ? find_shape_rule(a) : nullptr;
+  if (rule && rule->split > 0) {
+    s = rule->split;
+  } else if (variant >= kFirstPP && variant < kVar16 && requested_split <= 0) {
     const int tiles = a.tilesM * a.tilesN;
     s = tiles < num_cus() ? pp_splits(tiles, a.nk) : 1;
   } else {

@@ -72,7 +72,7 @@ def bench_conv(tag, variants, splits):
     s, up, epi = kv["s"], kv["up"], kv["epi"]
     rows_out = n * H * W_ * (4 if up else 1) // (s * s)
     x = torch.randn(n * H * W_, cin, device=DEV).half()
-    w = (torch.randn(cout, 9 * cin, device=DEV) * (9 * cin) ** -0.5).half()
+    w = (torch.randn(cout, (16 if up == 2 else 9) * cin, device=DEV) * (9 * cin) ** -0.5).half()   # (up = 2: the four-phase image, [4][cout][4 cin])
     bias = torch.randn(cout, device=DEV)
     res = torch.randn(rows_out, cout, device=DEV).half()
     rowvec = torch.randn(16, cout, device=DEV)
