@@ -440,6 +440,9 @@ int rcdm_pack_f16(const float* src, void* dst, size_t n, void* stream);
 int rcdm_pack_conv3x3(const float* w, int32_t c_out, int32_t c_in, int32_t cin_pad, void* dst,
                       void* stream);
 int rcdm_pack_conv3x3_up2(const float* w, int32_t c_out, int32_t c_in, void* dst, void* stream);
+/* C[n][m] = A[n][k] B[k][m], fp32 row-major, device to device: composition of two linear maps at pack time (proj_out behind
+ * ff.net.2, the context stacks' projections) before the product is rounded to f16.  Fixed summation order; not a hot-path call. */
+int rcdm_matmul_f32(const float* A, const float* B, float* C, int32_t n, int32_t k, int32_t m, void* stream);
 int rcdm_pack_geglu_rows(const float* w, const float* bias, int32_t n_out /*8C*/, int32_t K,
                          void* w_dst, float* bias_dst, void* stream);
 

@@ -47,10 +47,11 @@ class _ContextStack(nn.Module):
         E = self.hidden_dim
         with torch.no_grad():
             wt, bt, wv, bv, win, bin_, wo, bo = [p.detach().float() for p in ps]
-            wq = (win[:E] @ wt).contiguous()
-            bq = (win[:E] @ bt + bin_[:E]).contiguous()
-            wkv = (win[E:] @ wv).contiguous()
-            bkv = (win[E:] @ bv + bin_[E:]).contiguous()
+            mm = hip.matmul_f32 if wt.is_cuda else torch.matmul   # (the library's own fp32 kernel on the GPU path)
+            wq = mm(win[:E], wt).contiguous()
+            bq = (mm(win[:E], bt) + bin_[:E]).contiguous()
+            wkv = mm(win[E:], wv).contiguous()
+            bkv = (mm(win[E:], bv) + bin_[E:]).contiguous()
             h = lambda w: w.to(torch.float16).contiguous()
             packed = dict(wq=h(wq), bq=bq, wkv=h(wkv), bkv=bkv, wo=h(wo), bo=bo.contiguous())
         self._packed = (key, packed)

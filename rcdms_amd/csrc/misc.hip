@@ -250,6 +250,35 @@ __global__ void pack_conv3x3_up2_kernel(const float* __restrict__ w, int c_out, 
     dst[i] = (f16)acc;
   }
 }
+// C[n][m] = A[n][k] B[k][m], all fp32 row-major: weight COMPOSITION at pack time (two linear maps in a row folded into one
+// matrix before it is rounded to f16 — Packer.ffz, the context stacks); 32x32 tiles through LDS, fixed summation order.
+// Not a hot-path kernel: a few GFLOP once per model load.
+__global__ __launch_bounds__(256) void matmul_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ C, int n, int k, int m) {
+  __shared__ float sa[32][33], sb[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8 threads, 4 output rows each
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < k; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = ty + 8 * i;
+      sa[r][tx] = (r0 + r < n && k0 + tx < k) ? A[(size_t)(r0 + r) * k + k0 + tx] : 0.f;
+      sb[r][tx] = (k0 + r < k && c0 + tx < m) ? B[(size_t)(k0 + r) * m + c0 + tx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      const float b = sb[kk][tx];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(sa[ty + 8 * i][kk], b, acc[i]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (r0 + ty + 8 * i < n && c0 + tx < m) C[(size_t)(r0 + ty + 8 * i) * m + c0 + tx] = acc[i];
+}
 // packed row p: grp = p/32, j = p%32; source row = j<16 ? grp*16+j (hidden) : n_out/2 + grp*16 + (j-16) (gate)
 __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n_out, int K,
                                   f16* __restrict__ wd, float* __restrict__ bd) {
@@ -393,6 +422,12 @@ int rcdm_pack_conv3x3(const float* w, int32_t c_out, int32_t c_in, int32_t cin_p
   const size_t n = (size_t)c_out * 9 * cin_pad;
   hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, c_out, c_in, cin_pad,
                      (f16*)dst);
+  return rcdm_check_launch();
+}
+
+int rcdm_matmul_f32(const float* A, const float* B, float* C, int32_t n, int32_t k, int32_t m, void* stream) {
+  if (!A || !B || !C || n <= 0 || k <= 0 || m <= 0) return RCDM_EINVAL;
+  hipLaunchKernelGGL(matmul_f32_kernel, dim3((m + 31) / 32, (n + 31) / 32), dim3(256), 0, (hipStream_t)stream, A, B, C, n, k, m);
   return rcdm_check_launch();
 }
 

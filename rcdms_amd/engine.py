@@ -429,11 +429,11 @@ class Packer:
         wpo = self.f32(po_key)
         wpo = wpo.reshape(wpo.shape[0], -1)
         bpo = self.f32(po_bkey)
-        src = torch.cat([wpo @ w2, wpo], dim=1).contiguous()
+        src = torch.cat([hip.matmul_f32(wpo, w2), wpo], dim=1).contiguous()
         dst = torch.empty(src.shape, dtype=torch.float16, device=self.device)
         hip.pack_f16(src.data_ptr(), dst.data_ptr(), src.numel())
         self._tmp.append(src)
-        return _NS(W=dst, b=(wpo @ b2 + bpo).contiguous())
+        return _NS(W=dst, b=(hip.matmul_f32(wpo, b2) + bpo).contiguous())
 
     def conv3x3_up2(self, key):
         """Phase weights of an Upsample3D conv (rcdm_conv3x3 with upsample = 2): f16 [4][cout][4 * cin]."""

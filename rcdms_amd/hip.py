@@ -132,6 +132,7 @@ SYMBOLS = {
     "rcdm_mish": (C.c_int, [_P, _P, _SZ, _P]),
     "rcdm_pack_conv3x3": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "rcdm_pack_conv3x3_up2": (C.c_int, [_P, _I, _I, _P, _P]),
+    "rcdm_matmul_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "rcdm_conv3x3_up2_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "rcdm_pack_geglu_rows": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
     "rcdm_graph_begin_capture": (C.c_int, [_P]),
@@ -391,6 +392,20 @@ def pack_f16(src, dst, n, stream=None):
 
 def mish(x, y, n, stream=None):
     _check(load().rcdm_mish(x, y, n, stream_ptr() if stream is None else stream), "rcdm_mish")
+
+
+def matmul_f32(a, b):
+    """a [n][k] @ b [k][m] (or b [k]) in fp32 on the library's own kernel (rcdm_matmul_f32): weight composition at pack time."""
+    import torch
+    a = a.contiguous().float()
+    vec = b.dim() == 1
+    b2 = (b[:, None] if vec else b).contiguous().float()
+    n, k = a.shape
+    m = b2.shape[1]
+    assert b2.shape[0] == k and a.is_cuda and b2.is_cuda
+    c = torch.empty(n, m, dtype=torch.float32, device=a.device)
+    _check(load().rcdm_matmul_f32(a.data_ptr(), b2.data_ptr(), c.data_ptr(), n, k, m, stream_ptr()), "rcdm_matmul_f32")
+    return c[:, 0].contiguous() if vec else c
 
 
 def pack_conv3x3_up2(w, c_out, c_in, dst, stream=None):

@@ -386,7 +386,7 @@ def _emit_mid_attention(plan, pk, p, x, geo, out, groups):
     wv = pk.mat_f16(p + "to_v.weight")
     wo = pk.mat_f16(p + "to_out.0.weight")
     # softmax rows sum to one, so P (V0 + 1 bv^T) = P V0 + bv: the value bias moves into the output projection
-    bo = (pk.vec(p + "to_out.0.bias") + pk.f32(p + "to_out.0.weight") @ pk.vec(p + "to_v.bias")).contiguous()
+    bo = (pk.vec(p + "to_out.0.bias") + hip.matmul_f32(pk.f32(p + "to_out.0.weight"), pk.vec(p + "to_v.bias"))).contiguous()
     q = plan.rows("vae_q", geo.M, C, unique=True)
     k = plan.rows("vae_k", geo.M, C, unique=True)
     emit_gemm(plan, a, wq, C, C, q, bias=bq)

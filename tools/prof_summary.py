@@ -37,7 +37,7 @@ def main():
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else None
     # one-off kernels of model construction (weight init, packing, host-tensor copies) are not part of a denoising step
     setup = ("pack_", "distribution_elementwise", "vectorized_elementwise", "CatArrayBatchedCopy", "copyBuffer", "fillBuffer",
-             "elementwise_kernel", "xattn_pack", "reduce_kernel<")
+             "elementwise_kernel", "xattn_pack", "reduce_kernel<", "matmul_f32_kernel")
     n_setup = sum(1 for name, _ in rows if any(k in name for k in setup))
     t_setup = sum(d for name, d in rows if any(k in name for k in setup))
     rows = [(n, d) for n, d in rows if not any(k in n for k in setup)]
