@@ -390,6 +390,19 @@ def test_conv3x3_upsample_phase_form(hiplib, n_img, H, W, cin, cout, variant, sp
     assert diff <= 4e-3 * ref.abs().max().item(), diff
 
 
+@pytest.mark.parametrize("n,k,m", [(640, 2560, 640), (33, 70, 1), (5, 1, 97), (1280, 1280, 5120)])
+def test_matmul_f32_pack_kernel(hiplib, n, k, m):
+    """rcdm_matmul_f32 (weight composition at pack time) against a float64 product; ragged sizes, a vector right side."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(n + k + m)
+    a = torch.randn(n, k, generator=g)
+    b = torch.randn(k, generator=g) if m == 1 else torch.randn(k, m, generator=g)
+    got = hip.matmul_f32(a.to(DEV), b.to(DEV)).cpu()
+    ref = (a.double() @ b.double()).float()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() <= 2e-5 * (k ** 0.5) * max(ref.abs().max().item(), 1.0)
+
+
 def test_conv3x3_upsample_phase_form_refusals(hiplib):
     """Shapes and epilogues the phase form does not take are refused by rcdm_conv3x3 and reported by the query."""
     from rcdms_amd import hip
