@@ -13,7 +13,7 @@ from tools.kbench import timeit  # noqa: E402
 
 DEV = "cuda"
 SHAPES = [("L1 ff-out", 10240, 640, 2560, 5), ("L2 ff-out", 2560, 1280, 5120, 5), ("L1 CxC", 10240, 640, 640, 5),
-          ("L2 CxC", 2560, 1280, 1280, 5), ("L3 CxC", 640, 1280, 1280, 5), ("L3 ff-out", 640, 1280, 5120, 5)]
+          ("L2 CxC", 2560, 1280, 1280, 5), ("L3 CxC", 640, 1280, 1280, 5), ("L3 ff-out", 640, 1280, 5120, 5), ("L1 ffz", 10240, 640, 3200, 5), ("L2 ffz", 2560, 1280, 6400, 5)]
 
 
 def main():
