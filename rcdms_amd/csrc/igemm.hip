@@ -750,13 +750,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
 
 // variant: 1 = 128x128 (2 blocks/CU), 2 = 256x256 (1), 3 = 64x64 two-slot ring (4), 4 = 64x64 four-slot ring (2),
 // 5 = 128x64 (3); 6 / 7 / 8 = the ping-pong kernel of igemm8.hip at 160x320 / 160x256 / 256x256; 9 = the 160x160 kernel of
-// igemm16.hip (2)   (-1 = heuristic)
+// igemm16.hip (2); 10 = 128x64 with a three-slot ring (2; GEMMs)   (-1 = heuristic)
 int g_force_variant = -1;
 struct TileCfg { int bm, bn, blocks_per_cu; };
 constexpr int kFirstPP = 6;
 constexpr int kVar16 = 9;  // igemm16.hip: 160x160, two blocks per CU
-const TileCfg kTiles[10] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}, {64, 64, 4}, {64, 64, 2}, {128, 64, 3},
-                            {160, 320, 1}, {160, 256, 1}, {256, 256, 1}, {160, 160, 2}};
+// 10: the igemm_dma loop at 128x64 with a THREE-slot LDS ring, two blocks per CU (GEMMs only; a conv runs as 5).  Measured
+// in the replayed graph (profiles/r4_shape_rules_ab.txt): -0.09 ms per step on the thirty-five N = C = K = 1280 projections of
+// the 16x16 level, worse everywhere else — as were a four-slot 128x64 ring and a three-slot 128x128 ring (one block per CU
+// each; built, tested, removed): one more stage in flight pays only where it does not cost the third co-resident block
+// more than the latency it hides.
+constexpr int kFirstDeep = 10, kNumVariants = 11;
+const TileCfg kTiles[kNumVariants] = {{128, 128, 2}, {128, 128, 2}, {256, 256, 1}, {64, 64, 4}, {64, 64, 2}, {128, 64, 3},
+                                      {160, 320, 1}, {160, 256, 1}, {256, 256, 1}, {160, 160, 2},
+                                      {128, 64, 2}};
+inline bool is_pp(int v) { return v >= kFirstPP && v < kVar16; }
+inline bool is_dma(int v) { return v < kFirstPP || v >= kFirstDeep; }
 int g_pp_mode = -1;  // RCDM_PP=0: never pick the ping-pong kernel (A/B switch)
 int g_num_cus = 0;
 long long* g_trace = nullptr;
@@ -845,7 +854,7 @@ bool pick_16(const IgemmArgs& a) {
   return a.M >= 5120 && a.M < 20480 && a.N >= 640 && a.N <= 1280;
 }
 
-// Per-shape overrides of the heuristics below: {taps, M, N, C_in} -> tile variant (1 .. 9) and split-K factor (0 = that
+// Per-shape overrides of the heuristics below: {taps, M, N, C_in} -> tile variant (1 .. 10) and split-K factor (0 = that
 // variant's own heuristic).  kShapeRules holds what tools/autotune.py found AND a same-box A/B of the whole step
 // confirmed; RCDM_SHAPE_RULES="taps,M,N,Cin,variant,split;..." adds rules at run time (first match wins: the environment's
 // rules are looked at first), RCDM_SHAPE_RULES=off ignores the table — for tuning another chip or another model without
@@ -858,6 +867,7 @@ const ShapeRule kShapeRules[] = {
     {9, 40960, 320, 640, kVar16, 1},   //   160x320 ping-pong tile (-3 % back to back, -0.15 ms per step together in the graph)
     {9, 40960, 320, 960, kVar16, 1},
     {9, 20480, 320, 320, kVar16, 0},   // ... and of the shared-prefix half batch
+    {1, 2560, 1280, 1280, 10, 0},      // the N = C projections of the 16x16 level (to_out, proj_in, to_q) on the three-slot 128x64 ring: -0.09 ms
     {1, 640, 1280, 2560, 3, 3},        // 1x1 shortcuts of the 8x8 / 16x16 up blocks: 64x64 tiles split 3 ways / 128x64 tiles
     {1, 2560, 1280, 2560, 5, 0},
     {0, 0, 0, 0, 0, 0},   // (terminator)
@@ -876,7 +886,7 @@ const ShapeRule* find_shape_rule(const IgemmArgs& a) {
         ShapeRule r{};
         int used = 0;
         if (sscanf(e, "%d,%d,%d,%d,%d,%d%n", &r.taps, &r.M, &r.N, &r.Cin, &r.variant, &r.split, &used) == 6 && r.variant >= 1 &&
-            r.variant <= 9 && r.split >= 0)
+            r.variant < kNumVariants && r.split >= 0)
           env_rules[n++] = r;
         e += used;
         while (*e && *e != ';') ++e;
@@ -890,8 +900,8 @@ const ShapeRule* find_shape_rule(const IgemmArgs& a) {
   const int taps = a.Ktot / a.Cin;
   auto fits = [&](const ShapeRule& r) {
     if (r.taps != taps || r.M != a.M || r.N != a.N || r.Cin != a.Cin) return false;
-    if (a.stat_out && r.variant > 5) return false;
-    if (a.lnx_stat && r.variant >= kFirstPP && r.variant < kVar16) return false;
+    if (a.stat_out && !is_dma(r.variant)) return false;
+    if (a.lnx_stat && is_pp(r.variant)) return false;
     if ((a.stat_out || a.lnx_stat) && r.split > 1) return false;
     return true;
   };
@@ -975,7 +985,7 @@ int fill_common(IgemmArgs& a, int requested_split, int* variant_out = nullptr) {
   const ShapeRule* rule = (g_force_variant == 99 && requested_split <= 0) ? find_shape_rule(a) : nullptr;
   if (rule && rule->split > 0) {
     s = rule->split;
-  } else if (variant >= kFirstPP && variant < kVar16 && requested_split <= 0) {
+  } else if (is_pp(variant) && requested_split <= 0) {
     const int tiles = a.tilesM * a.tilesN;
     s = tiles < num_cus() ? pp_splits(tiles, a.nk) : 1;
   } else {
@@ -1016,6 +1026,7 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   constexpr int LDS_64 = 2 * (64 + 64) * 128 + LTAB;      // 32 KB  (four blocks per CU)
   constexpr int LDS_64D = 4 * (64 + 64) * 128 + LTAB;     // 64 KB  (three steps in flight)
   constexpr int LDS_128x64 = 2 * (128 + 64) * 128 + LTAB; // 48 KB  (three blocks per CU)
+  constexpr int LDS_128x64_3 = 3 * (128 + 64) * 128 + LTAB;   // 72 KB (two)
   static bool attr_set[64] = {};
   if (rcdm_first_on_device(attr_set)) {
     set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, false>, LDS_128);
@@ -1029,6 +1040,13 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
     set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4, true>, LDS_64D);
     set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2, true>, LDS_128x64);
     if constexpr (TAPS == 1) {
+#define RCDM_DEEP_LDS(BM, BN, NS, LDS)                                                      \
+      set_lds(igemm_dma_kernel<TAPS, BM, BN, 2, 2, NS, false>, LDS);                        \
+      set_lds(igemm_dma_kernel<TAPS, BM, BN, 2, 2, NS, true>, LDS);                         \
+      set_lds(igemm_dma_kernel<TAPS, BM, BN, 2, 2, NS, true, 1>, LDS);                      \
+      set_lds(igemm_dma_kernel<TAPS, BM, BN, 2, 2, NS, true, 2>, LDS)
+      RCDM_DEEP_LDS(128, 64, 3, LDS_128x64_3);
+#undef RCDM_DEEP_LDS
       set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, true, 1>, LDS_128);
       set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2, true, 1>, LDS_256);
       set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2, true, 1>, LDS_64);
@@ -1050,7 +1068,7 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   }
   a.trace = g_trace;
   a.dbg = 0;
-  if (a.stat_out && (variant >= kFirstPP || a.splits > 1 || (a.epi & RCDM_EPI_GEGLU) || a.stat_parts != a.tilesN))
+  if (a.stat_out && (!is_dma(variant) || a.splits > 1 || (a.epi & RCDM_EPI_GEGLU) || a.stat_parts != a.tilesN))
     return RCDM_ESHAPE;
   if ((a.stat_out || a.lnx_stat) && TAPS != 1) return RCDM_ESHAPE;
   if (a.lnx_stat && (a.splits > 1 || !a.lnx_S || a.lnx_parts < 1 || a.lnx_parts > kLnxMaxParts)) return RCDM_ESHAPE;
@@ -1067,7 +1085,7 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
     }
     return rc;
   }
-  if (variant >= kFirstPP) {
+  if (is_pp(variant)) {
     static int rotate = -1;
     if (rotate < 0) {
       const char* e = getenv("RCDM_PP_ROTATE");
@@ -1118,7 +1136,9 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
     if (e16) hipLaunchKernelGGL((igemm_dma_kernel<TAPS, BM, BN, WM, WN, NS, true>), grid, dim3(THREADS), LDS, stream, a); \
     else hipLaunchKernelGGL((igemm_dma_kernel<TAPS, BM, BN, WM, WN, NS, false>), grid, dim3(THREADS), LDS, stream, a);    \
   } while (0)
+  if (TAPS != 1 && variant >= kFirstDeep) variant = 5;
   switch (variant) {
+    case 10: if constexpr (TAPS == 1) { RCDM_IGEMM_LAUNCH(128, 64, 2, 2, 3, 256, LDS_128x64_3); } break;
     case 2: RCDM_IGEMM_LAUNCH(256, 256, 2, 4, 2, 512, LDS_256); break;
     case 3: RCDM_IGEMM_LAUNCH(64, 64, 2, 2, 2, 256, LDS_64); break;
     case 4: RCDM_IGEMM_LAUNCH(64, 64, 2, 2, 4, 256, LDS_64D); break;
@@ -1224,7 +1244,7 @@ int rcdm_conv3x3_up2_supported(const rcdm_conv3x3_desc* d) {
 }
 
 int rcdm_set_igemm_variant(int32_t v) {
-  if (v < -1 || v > 9) return RCDM_EINVAL;
+  if (v < -1 || v >= kNumVariants) return RCDM_EINVAL;
   g_force_variant = v < 0 ? 99 : v;
   return RCDM_OK;
 }

@@ -61,7 +61,7 @@ def ws(nbytes):
     (260, 64, 64, 1 | 2 | 4, 1),     # row vector with fewer rows per sample (100) than a 128-row tile: in-place reads
     (400, 320, 128, 1 | 2 | 4, 1),
 ])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm(hiplib, M, N, K, epi, split, variant):
     from rcdms_amd import hip
     hip.set_igemm_variant(variant)
@@ -268,7 +268,7 @@ def test_gemm_pingpong_bitwise_vs_128(hiplib, variant):
     close(outs[0], outs[3].float(), rel=2e-3, abs_frac=1e-3)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("split", [1, 2])
 def test_gemm_geglu(hiplib, split, variant):
     from rcdms_amd import hip
@@ -302,7 +302,7 @@ def test_gemm_geglu(hiplib, split, variant):
     (2, 1, 8, 8, 320, 320, 1, 0, 4),    # split-K
     (2, 5, 16, 16, 128, 320, 1, 0, 0),  # 2560 pixels: several 160-row tiles, 18 k-steps, heuristic split
 ])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split, variant):
     from rcdms_amd import hip
     hip.set_igemm_variant(variant)

@@ -3,7 +3,7 @@
 applies rstd (x W'^T) - rstd mean S + b' in its epilogue.  Reference (fp32 torch, the arithmetic of the reference's
 nn.LayerNorm + nn.Linear, attention.py:482-514 / motion_module.py:236-243 with PositionalEncoding :265-267):
     x = f16(A_p W_p^T + b_p + res);  y = epi(LayerNorm(x) (+ pe_f) W^T + b).
-Every tile shape (variants 1-9 as consumer, 1-5 as producer), plain / GEGLU / row-vector epilogues, ragged M, dup rows,
+Every tile shape (variants 1-10 as consumer, 1-5 and 10 as producer), plain / GEGLU / row-vector epilogues, ragged M, dup rows,
 rows whose mean is large against their spread (the cancellation case of E[x^2] - mean^2 and of the f16-staged x W'^T)."""
 import pytest
 import torch
@@ -35,7 +35,7 @@ def _producer(hip, Ap, Wp, bp, res, M, C, Kp, variant, dup=0):
     return x, stat, parts
 
 
-@pytest.mark.parametrize("pvariant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("pvariant", [1, 2, 3, 4, 5, 10])
 @pytest.mark.parametrize("M,C", [(640, 1280), (1000, 640), (300, 64)])
 def test_row_statistics(hiplib, M, C, pvariant):
     """Producer side alone: the partial slots of a row sum to (sum, sum of squares) of the f16 values stored to that row."""
@@ -70,7 +70,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("cvariant", [-1, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("cvariant", [-1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("M,C,N,form,shift", CASES)
 def test_gemm_lnx_vs_reference(hiplib, M, C, N, form, shift, cvariant):
     from rcdms_amd import hip
