@@ -123,6 +123,11 @@ int rcdm_gemm_lnx(const rcdm_gemm_desc* d, const rcdm_lnx* x, const void* A, con
  * RCDM_IGEMM=dma128|dma256|dma64 overrides), tile (pixels x channels): 1 = 128x128, 2 = 256x256, 3 = 64x64,
  * 4 = 64x64 with a four-slot LDS ring, 5 = 128x64.
  * Changes the workspace size a shape needs: query rcdm_*_workspace_bytes after setting it. */
+/* per-shape overrides of the tile heuristics: "taps,M,N,Cin,variant,split;..." (taps 1 | 9, variant 1 .. 10, split 0 = that
+ * variant's heuristic), looked at before the library's own measured table; "off" ignores the table, "" adds nothing, NULL goes
+ * back to the environment variable RCDM_SHAPE_RULES (same syntax).  For tuning another chip / model without a rebuild
+ * (tools/tune_rules.py).  Changes workspace sizes like rcdm_set_igemm_variant. */
+int rcdm_set_shape_rules(const char* rules);
 int rcdm_set_igemm_variant(int32_t variant);  /* 6 / 7 / 8: ping-pong kernel at 160x320 / 160x256 / 256x256; 9: igemm16 (160x160); 10: 128x64 with a three-slot LDS ring (GEMMs; a conv runs as 5) */
 /* Tuning switch: 0 = the shape heuristic never picks the 8-wave ping-pong kernel (igemm8.hip), 1 = it may
  * (default; environment RCDM_PP=0 sets the initial state).  Used for same-process A/B timing. */

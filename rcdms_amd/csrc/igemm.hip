@@ -868,21 +868,36 @@ const ShapeRule kShapeRules[] = {
     {9, 40960, 320, 960, kVar16, 1},
     {9, 20480, 320, 320, kVar16, 0},   // ... and of the shared-prefix half batch
     {1, 2560, 1280, 1280, 10, 0},      // the N = C projections of the 16x16 level (to_out, proj_in, to_q) on the three-slot 128x64 ring: -0.09 ms
-    {1, 640, 1280, 2560, 3, 3},        // 1x1 shortcuts of the 8x8 / 16x16 up blocks: 64x64 tiles split 3 ways / 128x64 tiles
-    {1, 2560, 1280, 2560, 5, 0},
+    {1, 640, 1280, 2560, 3, 3},        // 1x1 shortcuts of the 8x8 up blocks: 64x64 tiles split 3 ways
+    // tools/tune_rules.py (every shape timed inside the step's launch sequence), then tools/ab_rules.sh: -0.07 ms together
+    {1, 2560, 1280, 6400, kVar16, 0},  // proj_out-composed feed-forward GEMMs (K = 5C): 16x16 level on 160x160 tiles,
+    {1, 10240, 640, 3200, 1, 0},       //   32x32 level on 128x128, 8x8 level on the three-slot 128x64 ring
+    {1, 640, 1280, 6400, 10, 0},
+    {1, 2560, 1280, 2560, 10, 0},      // 1x1 shortcuts / downsample-level projections of the 16x16 level: three-slot 128x64 ring
+    {1, 2560, 1280, 1920, 10, 0},
+    {1, 2560, 1280, 640, 10, 0},
+    {1, 40960, 320, 640, kVar16, 0},   // 1x1 shortcuts of the 64x64 up blocks on 160x160 tiles
+    {1, 40960, 320, 960, kVar16, 0},
     {0, 0, 0, 0, 0, 0},   // (terminator)
 };
+constexpr int kMaxEnvRules = 128;
+ShapeRule g_env_rules[kMaxEnvRules];
+int g_n_env = -1;            // -1: RCDM_SHAPE_RULES not parsed yet
+bool g_rule_table_on = true;
+char g_rules_text[8192] = "";
+bool g_rules_from_api = false;
 const ShapeRule* find_shape_rule(const IgemmArgs& a) {
-  static ShapeRule env_rules[32];
-  static int n_env = -1;
-  static bool table_on = true;
+  ShapeRule* env_rules = g_env_rules;
+  int& n_env = g_n_env;
+  bool& table_on = g_rule_table_on;
   if (n_env < 0) {
     int n = 0;
-    const char* e = getenv("RCDM_SHAPE_RULES");
+    const char* e = g_rules_from_api ? g_rules_text : getenv("RCDM_SHAPE_RULES");
+    table_on = true;
     if (e && !strcmp(e, "off")) {
       table_on = false;
     } else if (e) {
-      while (*e && n < 32) {
+      while (*e && n < kMaxEnvRules) {
         ShapeRule r{};
         int used = 0;
         if (sscanf(e, "%d,%d,%d,%d,%d,%d%n", &r.taps, &r.M, &r.N, &r.Cin, &r.variant, &r.split, &used) == 6 && r.variant >= 1 &&
@@ -1246,6 +1261,14 @@ int rcdm_conv3x3_up2_supported(const rcdm_conv3x3_desc* d) {
 int rcdm_set_igemm_variant(int32_t v) {
   if (v < -1 || v >= kNumVariants) return RCDM_EINVAL;
   g_force_variant = v < 0 ? 99 : v;
+  return RCDM_OK;
+}
+
+int rcdm_set_shape_rules(const char* rules) {
+  if (rules && strlen(rules) >= sizeof(g_rules_text)) return RCDM_EINVAL;
+  g_rules_from_api = rules != nullptr;
+  if (rules) strcpy(g_rules_text, rules);
+  g_n_env = -1;   // parsed again at the next launch
   return RCDM_OK;
 }
 

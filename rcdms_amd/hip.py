@@ -90,6 +90,7 @@ SYMBOLS = {
     "rcdm_gemm_lnx": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(Lnx), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_gemm_workspace_bytes": (_SZ, [C.POINTER(GemmDesc)]),
     "rcdm_set_igemm_variant": (C.c_int, [_I]),
+    "rcdm_set_shape_rules": (C.c_int, [C.c_char_p]),
     "rcdm_set_igemm_pingpong": (C.c_int, [_I]),
     "rcdm_debug_set_igemm_trace": (C.c_int, [_P]),
     "rcdm_debug_set_attn_trace": (C.c_int, [_P]),
@@ -194,6 +195,11 @@ def ptr(t):
 
 # ------------------------------------------------------------------------------------------------
 # thin typed wrappers (all enqueue on torch's current stream unless `stream` is given)
+
+def set_shape_rules(rules):
+    """Per-shape tile rules "taps,M,N,Cin,variant,split;..." ("off": no table; None: back to RCDM_SHAPE_RULES)."""
+    _check(load().rcdm_set_shape_rules(None if rules is None else rules.encode()), "rcdm_set_shape_rules")
+
 
 def set_igemm_variant(v):
     _check(load().rcdm_set_igemm_variant(v), "rcdm_set_igemm_variant")

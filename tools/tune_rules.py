@@ -1,0 +1,125 @@
+#!/usr/bin/env python
+"""In-sequence tile tuning: every GEMM / conv3x3 of the bench workload's launch plan is timed INSIDE the step's launch
+sequence (one execution per pass between two events, operands as cold as in the replayed graph — tools/autotune.py times
+each shape back to back, operands hot, and mis-ranks the latency-bound shapes), once per candidate tile variant forced on
+all shapes at a time through rcdm_set_shape_rules.  Prints, per shape, the library's choice against the best candidate
+and a RCDM_SHAPE_RULES string of the gains; confirm with tools/ab_rules.sh before a rule goes into kShapeRules.
+usage: python tools/tune_rules.py [--latent 64] [--passes 5] [--min-gain-us 1.0]"""
+import argparse
+import os
+import re
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rcdms_amd import hip  # noqa: E402
+
+CAND = {1: [1, 2, 3, 4, 5, 9, 10], 9: [1, 2, 5, 6, 7, 8, 9]}
+
+
+def shape_of(tag):
+    if tag.startswith("gemm "):
+        kv = {k: int(v) for k, v in re.findall(r"(\w+)=(\d+)", tag)}
+        return (1, kv["M"], kv["N"], kv["K"])
+    if tag.startswith("conv3x3 "):
+        n, H, W = (int(v) for v in re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
+        cin, cout = (int(v) for v in re.search(r"(\d+)->(\d+)", tag).groups())
+        kv = {k: int(v) for k, v in re.findall(r"(\w+)=(\d+)", tag)}
+        if kv["up"] == 2:
+            return None
+        rows = n * H * W * (4 if kv["up"] else 1) // (kv["s"] * kv["s"])
+        return (9, rows, cout, cin)
+    return None
+
+
+def time_passes(plan, passes):
+    n = len(plan.ops)
+    times = [[] for _ in range(n)]
+    for p in range(passes + 1):
+        evs = []
+        for op in plan.ops:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                op()
+            except hip.RcdmError:
+                evs.append(None)
+                continue
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        if p == 0:
+            continue
+        for i, ev in enumerate(evs):
+            times[i].append(float("inf") if ev is None else ev[0].elapsed_time(ev[1]) * 1e3)
+    return [statistics.median(t) for t in times]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--passes", type=int, default=5)
+    ap.add_argument("--min-gain-us", type=float, default=1.0)
+    a = ap.parse_args()
+    import bench
+    from rcdms_amd import synth
+    from rcdms_amd.sampler import DenoiseLoop
+    from rcdms_amd.scheduler import DDIMScheduler
+    dev = torch.device("cuda", 0)
+    model = bench.build_model(dev)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    story = synth.synthetic_story(stories=1, latent_hw=(a.latent, a.latent), ctx_len=85, seed=42)
+    loop = DenoiseLoop(model, 1, 5, a.latent, a.latent, 85, 2.0, sched, 4)
+    loop.load(story["latents"], story["mask"], story["masked_latents"], story["ctx"])
+    loop.run(use_graph=False)
+    plan = loop.prog.plan
+    for name in ("splitk_ws", "splitk_ws_side"):   # another variant may split where the planned one does not
+        if name in plan.bufs:
+            b = plan.bufs[name]
+            b.t = torch.zeros(1 << 30, dtype=torch.uint8, device=dev)
+            b.nbytes = 1 << 30
+    shapes = [shape_of(t) for t in plan.tags]
+    distinct = sorted({s for s in shapes if s})
+    with torch.cuda.stream(loop.prog.stream):
+        hip.set_shape_rules("")
+        base = time_passes(plan, a.passes)
+        res = {}
+        for taps, cands in CAND.items():
+            for v in cands:
+                hip.set_shape_rules(";".join(f"{t},{M},{N},{C},{v},0" for t, M, N, C in distinct if t == taps))
+                res[(taps, v)] = time_passes(plan, a.passes)
+        hip.set_shape_rules(None)
+    by_tag = {}
+    for i, (tag, s) in enumerate(zip(plan.tags, shapes)):
+        if s:
+            by_tag.setdefault((tag, s), []).append(i)
+    rules, total = {}, 0.0
+    print(f"{'op':62s} {'n':>3s} {'library':>9s} | best candidate")
+    for (tag, s), idx in sorted(by_tag.items(), key=lambda kv: -sum(base[i] for i in kv[1])):
+        b = sum(base[i] for i in idx) / len(idx)
+        best_v, best_t = None, b
+        for v in CAND[s[0]]:
+            t = sum(res[(s[0], v)][i] for i in idx) / len(idx)
+            if t < best_t:
+                best_v, best_t = v, t
+        gain = (b - best_t) * len(idx)
+        flag = ""
+        if best_v is not None and b - best_t >= a.min_gain_us and (b - best_t) / b >= 0.03:
+            flag = "  <--"
+            # several tags can share a shape (epilogue variants): keep the rule only if no tag of the shape loses
+            rules.setdefault(s, []).append((best_v, gain))
+            total += gain
+        print(f"{tag:62s} {len(idx):3d} {b:8.1f}us | " + (f"v{best_v}: {best_t:7.1f}us ({gain:6.1f} us per step){flag}" if best_v else "-"))
+    print(f"sum of the flagged gains: {total / 1e3:.3f} ms per step (in-sequence timing)")
+    out = []
+    for s, lst in rules.items():
+        vs = {v for v, _ in lst}
+        if len(vs) == 1:
+            out.append(f"{s[0]},{s[1]},{s[2]},{s[3]},{vs.pop()},0")
+    print("RCDM_SHAPE_RULES=" + ";".join(out))
+
+
+if __name__ == "__main__":
+    main()
