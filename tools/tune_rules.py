@@ -16,7 +16,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rcdms_amd import hip  # noqa: E402
 
-CAND = {1: [1, 2, 3, 4, 5, 9, 10], 9: [1, 2, 5, 6, 7, 8, 9]}
+# (variant, split-K factor; 0 = the variant's own heuristic) candidates per tap count
+CAND = {1: [(v, 0) for v in (1, 2, 3, 4, 5, 9, 10)] + [(v, sp) for v in (1, 3, 5, 9, 10) for sp in (1, 2, 3, 4)],
+        9: [(v, 0) for v in (1, 2, 5, 6, 7, 8, 9)] + [(v, sp) for v in (1, 2, 8, 9) for sp in (1, 2, 4, 8)]}
 
 
 def shape_of(tag):
@@ -87,9 +89,9 @@ def main():
         base = time_passes(plan, a.passes)
         res = {}
         for taps, cands in CAND.items():
-            for v in cands:
-                hip.set_shape_rules(";".join(f"{t},{M},{N},{C},{v},0" for t, M, N, C in distinct if t == taps))
-                res[(taps, v)] = time_passes(plan, a.passes)
+            for v, sp in cands:
+                hip.set_shape_rules(";".join(f"{t},{M},{N},{C},{v},{sp}" for t, M, N, C in distinct if t == taps))
+                res[(taps, (v, sp))] = time_passes(plan, a.passes)
         hip.set_shape_rules(None)
     by_tag = {}
     for i, (tag, s) in enumerate(zip(plan.tags, shapes)):
@@ -111,13 +113,14 @@ def main():
             # several tags can share a shape (epilogue variants): keep the rule only if no tag of the shape loses
             rules.setdefault(s, []).append((best_v, gain))
             total += gain
-        print(f"{tag:62s} {len(idx):3d} {b:8.1f}us | " + (f"v{best_v}: {best_t:7.1f}us ({gain:6.1f} us per step){flag}" if best_v else "-"))
+        print(f"{tag:62s} {len(idx):3d} {b:8.1f}us | " + (f"v{best_v[0]} split {best_v[1]}: {best_t:7.1f}us ({gain:6.1f} us per step){flag}" if best_v else "-"))
     print(f"sum of the flagged gains: {total / 1e3:.3f} ms per step (in-sequence timing)")
     out = []
     for s, lst in rules.items():
         vs = {v for v, _ in lst}
         if len(vs) == 1:
-            out.append(f"{s[0]},{s[1]},{s[2]},{s[3]},{vs.pop()},0")
+            v, sp = vs.pop()
+            out.append(f"{s[0]},{s[1]},{s[2]},{s[3]},{v},{sp}")
     print("RCDM_SHAPE_RULES=" + ";".join(out))
 
 
