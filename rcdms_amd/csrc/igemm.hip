@@ -878,6 +878,25 @@ const ShapeRule kShapeRules[] = {
     {1, 2560, 1280, 640, 10, 0},
     {1, 40960, 320, 640, kVar16, 0},   // 1x1 shortcuts of the 64x64 up blocks on 160x160 tiles
     {1, 40960, 320, 960, kVar16, 0},
+    // the shapes only BASELINE config 1's plan has (b = 2 x 5 frames, 32x32 latents): tools/tune_rules.py --latent 32, confirmed
+    // together in the graph (183.1 -> 173.9 ms per 20-step story; profiles/r4_shape_rules_ab.txt)
+    {1, 2560, 640, 3200, 4, 0}, {1, 10240, 320, 1600, 10, 0}, {1, 2560, 640, 640, 4, 0}, {9, 160, 1280, 1280, 5, 0},
+    {1, 160, 1280, 6400, 10, 0}, {1, 160, 10240, 1280, 4, 0}, {9, 10240, 320, 640, kVar16, 0},
+    {1, 160, 1280, 2560, 10, 4}, {9, 10240, 320, 960, kVar16, 4}, {9, 2560, 640, 1920, kVar16, 0},
+    {1, 10240, 320, 320, 10, 0}, {9, 2560, 640, 1280, kVar16, 0}, {9, 2560, 640, 960, kVar16, 8},
+    {9, 5120, 320, 320, 1, 4}, {9, 640, 1280, 640, 1, 8}, {9, 2560, 640, 320, 1, 4}, {9, 640, 640, 640, 1, 8},
+    {9, 2560, 320, 320, kVar16, 8}, {1, 2560, 640, 1920, 4, 0}, {1, 640, 1280, 1920, 10, 4},
+    {9, 10240, 8, 320, kVar16, 8}, {1, 10240, 320, 960, 10, 0}, {1, 2560, 640, 1280, 4, 0}, {9, 5120, 320, 64, 5, 0},
+    {1, 2560, 640, 960, 4, 0}, {1, 5120, 320, 320, 4, 0}, {1, 640, 1280, 640, 4, 0}, {1, 2560, 640, 320, 4, 0},
+    // the shapes only BASELINE config 3's plan has (4 stories = b 8, 64x64 latents, L = 91): --stories 4 --ctx-len 91, confirmed
+    // together (2741 -> 2683 ms per story batch): at this batch the 160x160 two-blocks-per-CU kernel beats the ping-pong tiles on
+    // every conv of the 64x64 / 32x32 levels in the step's own sequence, not back to back
+    {1, 40960, 5120, 640, 2, 0}, {1, 10240, 1280, 6400, kVar16, 1}, {9, 40960, 640, 640, kVar16, 0},
+    {9, 163840, 320, 640, kVar16, 1}, {9, 163840, 320, 960, kVar16, 0}, {9, 40960, 640, 1920, kVar16, 1},
+    {9, 40960, 640, 1280, kVar16, 1}, {9, 40960, 640, 960, kVar16, 0}, {1, 10240, 1280, 1280, kVar16, 1},
+    {9, 40960, 640, 320, kVar16, 1}, {1, 10240, 1280, 2560, kVar16, 1}, {1, 40960, 640, 1920, kVar16, 0},
+    {1, 40960, 640, 1280, kVar16, 1}, {9, 81920, 320, 64, kVar16, 1}, {1, 10240, 1280, 1920, kVar16, 0},
+    {1, 40960, 640, 320, 5, 1}, {1, 81920, 320, 320, 5, 1}, {1, 10240, 1280, 640, kVar16, 0},
     {0, 0, 0, 0, 0, 0},   // (terminator)
 };
 constexpr int kMaxEnvRules = 128;

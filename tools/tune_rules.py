@@ -4,7 +4,7 @@ sequence (one execution per pass between two events, operands as cold as in the 
 each shape back to back, operands hot, and mis-ranks the latency-bound shapes), once per candidate tile variant forced on
 all shapes at a time through rcdm_set_shape_rules.  Prints, per shape, the library's choice against the best candidate
 and a RCDM_SHAPE_RULES string of the gains; confirm with tools/ab_rules.sh before a rule goes into kShapeRules.
-usage: python tools/tune_rules.py [--latent 64] [--passes 5] [--min-gain-us 1.0]"""
+usage: python tools/tune_rules.py [--latent 64] [--stories 1] [--ctx-len 85] [--passes 5] [--min-gain-us 1.0]"""
 import argparse
 import os
 import re
@@ -62,6 +62,8 @@ def time_passes(plan, passes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--stories", type=int, default=1)
+    ap.add_argument("--ctx-len", type=int, default=85)
     ap.add_argument("--passes", type=int, default=5)
     ap.add_argument("--min-gain-us", type=float, default=1.0)
     a = ap.parse_args()
@@ -72,8 +74,8 @@ def main():
     dev = torch.device("cuda", 0)
     model = bench.build_model(dev)
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
-    story = synth.synthetic_story(stories=1, latent_hw=(a.latent, a.latent), ctx_len=85, seed=42)
-    loop = DenoiseLoop(model, 1, 5, a.latent, a.latent, 85, 2.0, sched, 4)
+    story = synth.synthetic_story(stories=a.stories, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42)
+    loop = DenoiseLoop(model, a.stories, 5, a.latent, a.latent, a.ctx_len, 2.0, sched, 4)
     loop.load(story["latents"], story["mask"], story["masked_latents"], story["ctx"])
     loop.run(use_graph=False)
     plan = loop.prog.plan
