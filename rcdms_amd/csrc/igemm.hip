@@ -897,6 +897,8 @@ const ShapeRule kShapeRules[] = {
     {9, 40960, 640, 320, kVar16, 1}, {1, 10240, 1280, 2560, kVar16, 1}, {1, 40960, 640, 1920, kVar16, 0},
     {1, 40960, 640, 1280, kVar16, 1}, {9, 81920, 320, 64, kVar16, 1}, {1, 10240, 1280, 1920, kVar16, 0},
     {1, 40960, 640, 320, 5, 1}, {1, 81920, 320, 320, 5, 1}, {1, 10240, 1280, 640, kVar16, 0},
+    // BASELINE config 5 (stage-1 prior, 970 token rows): tools/tune_rules.py --prior, confirmed with tools/bench_prior.py (1.83 -> 1.92 stories/s)
+    {1, 970, 2048, 2048, 4, 0}, {1, 970, 6144, 2048, 5, 1}, {1, 10, 1280, 2048, 10, 4},
     {0, 0, 0, 0, 0, 0},   // (terminator)
 };
 constexpr int kMaxEnvRules = 128;

@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--stories", type=int, default=1)
     ap.add_argument("--ctx-len", type=int, default=85)
+    ap.add_argument("--prior", action="store_true", help="tune the stage-1 prior's step (config 5) instead of the UNet's")
     ap.add_argument("--passes", type=int, default=5)
     ap.add_argument("--min-gain-us", type=float, default=1.0)
     a = ap.parse_args()
@@ -72,13 +73,47 @@ def main():
     from rcdms_amd.sampler import DenoiseLoop
     from rcdms_amd.scheduler import DDIMScheduler
     dev = torch.device("cuda", 0)
+    if a.prior:
+        plan, stream = prior_plan(dev)
+        return tune(plan, stream, a)
     model = bench.build_model(dev)
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
     story = synth.synthetic_story(stories=a.stories, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42)
     loop = DenoiseLoop(model, a.stories, 5, a.latent, a.latent, a.ctx_len, 2.0, sched, 4)
     loop.load(story["latents"], story["mask"], story["masked_latents"], story["ctx"])
     loop.run(use_graph=False)
-    plan = loop.prog.plan
+    tune(loop.prog.plan, loop.prog.stream, a)
+
+
+def prior_plan(dev):
+    """BASELINE config 5 (tools/bench_prior.py): the stage-1 prior's step plan at the full 20-layer shape."""
+    import bench
+    from rcdms_amd.sampler import PriorLoop
+    from rcdms_amd.scheduler import UnCLIPScheduler
+    from src.models.myprior_transformer import MyPriorTransformer
+    mk = dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
+              temporal_position_encoding=True, temporal_position_encoding_max_len=5, temporal_attention_dim_div=1)
+    with torch.device("meta"):
+        m = MyPriorTransformer(num_attention_heads=32, attention_head_dim=64, num_layers=20, embedding_dim=1280,
+                               num_embeddings=91, additional_embeddings=6, unet_use_cross_frame_attention=False,
+                               unet_use_temporal_attention=False, use_motion_module=True, motion_module_type="Vanilla",
+                               motion_module_kwargs=mk)
+    m = m.to_empty(device=dev).eval()
+    bench.init_weights_(m)
+    B, T, E = 10, 91, 1280
+    g = torch.Generator(device=dev).manual_seed(42)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    mask = torch.ones(B, T, device=dev)
+    mask[:, 20:] = 0
+    loop = PriorLoop(m, 5, T, 4.0, UnCLIPScheduler(), 4)
+    loop.load(rn(5, E), rn(B, E), rn(B, T, E), rn(B, E), rn(B, E), mask, generator=g)
+    loop.run(use_graph=False)
+    prior_plan.keep = (m, loop)
+    return loop.prog.plan, torch.cuda.current_stream(dev)   # (the prior program launches on the caller's stream)
+
+
+def tune(plan, stream, a):
+    dev = torch.device("cuda", 0)
     for name in ("splitk_ws", "splitk_ws_side"):   # another variant may split where the planned one does not
         if name in plan.bufs:
             b = plan.bufs[name]
@@ -86,7 +121,7 @@ def main():
             b.nbytes = 1 << 30
     shapes = [shape_of(t) for t in plan.tags]
     distinct = sorted({s for s in shapes if s})
-    with torch.cuda.stream(loop.prog.stream):
+    with torch.cuda.stream(stream):
         hip.set_shape_rules("")
         base = time_passes(plan, a.passes)
         res = {}
