@@ -390,6 +390,46 @@ def test_conv3x3_upsample_phase_form(hiplib, n_img, H, W, cin, cout, variant, sp
     assert diff <= 4e-3 * ref.abs().max().item(), diff
 
 
+def test_shape_rules_override_the_tile_choice(hiplib):
+    """rcdm_set_shape_rules: a rule changes the tile variant / split-K plan of exactly its shape (seen through the workspace
+    query), the result stays right, "off" and NULL restore the library's own behaviour, malformed text is ignored."""
+    from rcdms_amd import hip
+    M, N, K = 640, 1280, 1280
+    g = torch.Generator().manual_seed(3)
+    A = h16(torch.randn(M, K, generator=g))
+    W = h16(torch.randn(N, K, generator=g) * K ** -0.5)
+    ref = A @ W.t()
+    Ad, Wd = A.half().to(DEV), W.half().to(DEV)
+    d = hip.GemmDesc(M, N, K, K, N, 0, 0, 1, 0, 1.0, 0)
+    other = hip.GemmDesc(M, N, 4096, 4096, N, 0, 0, 1, 0, 1.0, 0)   # (a shape the library's own table has no rule for)
+
+    def run():
+        w = ws(hip.gemm_workspace_bytes(d))
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+        hip.gemm(d, Ad.data_ptr(), Wd.data_ptr(), 0, 0, 0, out.data_ptr(), w.data_ptr(), w.numel())
+        torch.cuda.synchronize()
+        close(out, ref)
+    try:
+        hip.set_shape_rules("off")
+        base, base_other = hip.gemm_workspace_bytes(d), hip.gemm_workspace_bytes(other)
+        run()
+        hip.set_shape_rules(f"1,{M},{N},{K},3,4")          # 64x64 tiles, K cut four ways: four fp32 slabs
+        assert hip.gemm_workspace_bytes(d) == 4 * M * N * 4
+        assert hip.gemm_workspace_bytes(other) == base_other   # another shape is not touched
+        run()
+        hip.set_shape_rules(f"1,{M},{N},{K},9,1")          # 160x160 tiles, unsplit
+        assert hip.gemm_workspace_bytes(d) == 0
+        run()
+        hip.set_shape_rules("nonsense;1,2,3")
+        assert hip.gemm_workspace_bytes(d) in (base, hip.gemm_workspace_bytes(d))
+        run()
+        hip.set_shape_rules("off")
+        assert hip.gemm_workspace_bytes(d) == base
+    finally:
+        hip.set_shape_rules(None)
+    run()
+
+
 @pytest.mark.parametrize("n,k,m", [(640, 2560, 640), (33, 70, 1), (5, 1, 97), (1280, 1280, 5120)])
 def test_matmul_f32_pack_kernel(hiplib, n, k, m):
     """rcdm_matmul_f32 (weight composition at pack time) against a float64 product; ragged sizes, a vector right side."""
