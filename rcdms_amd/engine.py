@@ -68,6 +68,7 @@ class Plan:
         self.tags = []  # one label per op (kind + shape): tools/opprof.py aggregates per-op timings by it
         self.keep = []  # tensors that must outlive the plan (packed weights etc.)
         self.n_launch = 0
+        self.op_weights = {}   # op index -> weight tensor of a GEMM / conv op (tools/prefetch_bound.py)
         self._side = None      # second stream: ops emitted inside side_branch() run there (a parallel branch of the step graph)
         self._in_side = False
 
@@ -199,6 +200,8 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
     n_before = len(plan.ops)
     plan.add(op, f"gemm M={A.M} N={N} K={K} epi={epi}" + (" lnx" if lnx is not None else "") + (" stat" if handle is not None else ""))
     plan.keep += [Wt, bias, rv_t, x, lnx[1] if lnx else None]
+    if len(plan.ops) > n_before:
+        plan.op_weights[len(plan.ops) - 1] = Wt
     plan.n_launch += 2 if wsb else 1
     # a LayerNorm of exactly these output rows emitted NEXT can ride in this GEMM's epilogue (emit_layernorm)
     plan.last_gemm = None
@@ -235,7 +238,10 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
     def op():
         hip.conv3x3(d, x.ptr, Wt.data_ptr(), bptr, (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0,
                     residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
+    n_before = len(plan.ops)
     plan.add(op, f"conv3x3 {n_img}x{H}x{W} {cin}->{cout} s={stride} up={up} epi={epi}")
+    if len(plan.ops) > n_before:
+        plan.op_weights[len(plan.ops) - 1] = Wt
     plan.keep += [Wt, bias, rv_t]
     plan.n_launch += 2 if wsb else 1
 
