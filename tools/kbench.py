@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of single librcdm_hip kernels at the UNet's hot shapes (HIP-event timed, interleaved rounds).
-usage: python tools/kbench.py [gemm|conv|attn|norm|ff|chain|all] [--variants 0,1,2] [--rounds 5]"""
+usage: python tools/kbench.py [gemm|conv|attn|norm|ff|chain|ladder|all] [--variants 0,1,2] [--rounds 5]"""
 import argparse
 import os
 import sys
@@ -343,6 +343,40 @@ def bench_chain(rounds, only=""):
                   f"stats + rcdm_rowchain {medg2:7.1f}us (min {mng2:.1f}) {fl / medg2 / 1e6:6.0f}TF", flush=True)
 
 
+def bench_ladder(rounds):
+    """The guide's yardstick (cdna_hip_programming.md, "optimization ladder at 4096^3": 874 TFLOP/s for the 128x128 two-barrier
+    structure, ~1330 for the 256x256 8-phase + swizzle template, uniform random operands): rcdm_gemm at M = N = K = 4096 (and
+    8192), f16, operands uniform in [-1, 1), no epilogue, every tile variant of the library, unsplit and at its best split."""
+    names = {1: "dma 128x128", 2: "dma 256x256", 3: "dma 64x64 x4", 4: "dma 64x64", 5: "dma 128x64", 6: "pp 160x320", 7: "pp 160x256",
+             8: "pp 256x256", 9: "i16 160x160", 10: "dma 128x64 ring3", -1: "library's pick"}
+    for n in (4096, 8192):
+        A = (torch.rand(n, n, device=DEV) * 2 - 1).half()
+        W = (torch.rand(n, n, device=DEV) * 2 - 1).half()
+        out = torch.empty(n, n, device=DEV, dtype=torch.float16)
+        fl = 2.0 * n ** 3
+        print(f"ladder rcdm_gemm M = N = K = {n}, f16 uniform [-1, 1), epi 0   (guide: 874 step-3 / ~1330 8-phase @4096; ~1470 8-phase @8192)", flush=True)
+        for v in (-1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+            hip.set_igemm_pingpong(True)
+            hip.set_igemm_variant(v)
+            best = None
+            line = f"ladder {n:5d} v{v:<2d} {names[v]:18s} |"
+            for split in (1, 2):
+                d = hip.GemmDesc(n, n, n, n, n, 0, 0, 1, 0, 1.0, split)
+                try:
+                    wsb = hip.gemm_workspace_bytes(d)
+                    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+                    fn = lambda: hip.gemm(d, A.data_ptr(), W.data_ptr(), 0, 0, 0, out.data_ptr(), ws.data_ptr(), ws.numel())
+                    fn()
+                    med, mn = timeit(fn, rounds, inner=5)
+                except hip.RcdmError as e:
+                    line += f" split {split}: {str(e)[:30]} |"
+                    continue
+                line += f" split {split}: {med:8.1f}us {fl / med / 1e6:6.0f}TF (best {fl / mn / 1e6:6.0f}) |"
+                best = max(best or 0.0, fl / med / 1e6)
+            print(line + (f"  => {best:.0f} TF" if best else ""), flush=True)
+    hip.set_igemm_variant(-1)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -368,3 +402,5 @@ if __name__ == "__main__":
         bench_ff(a.rounds, a.only)
     if a.what in ("chain", "all"):
         bench_chain(a.rounds, a.only)
+    if a.what == "ladder":
+        bench_ladder(a.rounds)

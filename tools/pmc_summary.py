@@ -15,7 +15,7 @@ for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for kn, cn, v, gs, ws in c.execute(q):
         if filt and filt not in kn: continue
-        key = (kn.replace("(anonymous namespace)::", "").split("(")[0][:48], gs // max(ws, 1), cn)
+        key = (kn.replace("(anonymous namespace)::", "").split("(")[0][:80], gs // max(ws, 1), cn)
         agg[key][0] += 1; agg[key][1] += v
     for (kn, blocks, cn), (n, tot) in sorted(agg.items()):
-        print(f"{kn:50s} blocks={blocks:6d} {cn:28s} n={n:4d} avg={tot / n:16.1f}")
+        print(f"{kn:82s} blocks={blocks:6d} {cn:28s} n={n:4d} avg={tot / n:16.1f}")
