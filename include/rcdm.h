@@ -407,6 +407,18 @@ int rcdm_rows_to_ncfhw(const void* rows, int32_t ld, int32_t b, int32_t C, int32
 int rcdm_cfg_ddim_step(const void* eps, int32_t ld, float* latents, int32_t S, int32_t reps,
                        int32_t frames, int32_t H, int32_t W, float guidance_scale, const float* coef,
                        const int32_t* step_counter, void* stream);
+/* Fused classifier-free guidance + one PLMS step of diffusers 0.24.0 PNDMScheduler(skip_prk_steps=True) — the other scheduler
+ *   type RCDMsPipeline's constructor accepts (RCDMs_pipeline.py:72-79), stepped at :497 — in place on `latents`:
+ *   e = eps_u + s (eps_c - eps_u); e' = the linear-multistep combination of e with up to three stored predictions;
+ *   x' = sqrt(a'/a) x - (a' - a) e' / (a sqrt(1 - a') + sqrt(a (1 - a) a')).
+ *   table: device fp32 [n_calls][12], one row per model evaluation (n_calls = num_inference_steps + 1: the second
+ *   timestep is evaluated twice), as rcdms_amd.scheduler.PNDMScheduler.plms_table() lays it out:
+ *   (a, b, w_now, w1, w2, w3, slot_now, s1, s2, s3, mode, 0); history: device fp32 [5][S*4*f*H*W], caller-owned, carries
+ *   the stored predictions (slots 0..3) and the first sample (slot 4) between calls; no initialisation needed.
+ *   step_counter as in rcdm_cfg_ddim_step. */
+int rcdm_cfg_pndm_step(const void* eps, int32_t ld, float* latents, float* history, int32_t S, int32_t reps,
+                       int32_t frames, int32_t H, int32_t W, float guidance_scale, const float* table,
+                       const int32_t* step_counter, void* stream);
 /* Stage-1 prior, per step of prior_pipeline.py:311-344.
  * rcdm_prior_assemble: tok[(b, l)] (f16, B*L rows of C) <- base rows, except l == time_row <- temb (one fp32 row of C);
  *   x16[b] (f16, E) <- latents[b % n_lat] (fp32): the `torch.cat([latents] * 2)` of :314 and the sequence concat of

@@ -310,13 +310,62 @@ class DDIMOracle:
         return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
 
 
-def denoise_loop(sd, cfg, latents, mask, masked_latents, ctx, num_steps, guidance_scale, unet=None, callback=None):
+class PNDMOracle:
+    """diffusers 0.24.0 PNDMScheduler with skip_prk_steps=True (PLMS) — the other scheduler type the pipeline constructor
+    accepts (RCDMs_pipeline.py:72-79), with steps_offset forced to 1 (:84-97); defaults otherwise: set_alpha_to_one False,
+    epsilon prediction, "leading" spacing.  Third-party arithmetic, restated from the published class: parity unpinned.
+    Written as the textbook recurrence (one list of kept predictions), independently of rcdms_amd/scheduler.py."""
+
+    def __init__(self, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", num_train_timesteps=1000, steps_offset=1):
+        if beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        elif beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        else:
+            raise ValueError(beta_schedule)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.N, self.offset = num_train_timesteps, steps_offset
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n):
+        self.n = n
+        base = [i * (self.N // n) + self.offset for i in range(n)]
+        self.timesteps = torch.tensor(list(reversed(base[:-1] + [base[-2], base[-1]])), dtype=torch.int64)
+        self.kept, self.calls, self.first = [], 0, None
+
+    def _prev(self, x, t, t_prev, e):
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[t_prev] if t_prev >= 0 else self.alphas_cumprod[0]
+        den = a_t * (1 - a_p) ** 0.5 + (a_t * (1 - a_t) * a_p) ** 0.5
+        return (a_p / a_t) ** 0.5 * x - (a_p - a_t) * e / den
+
+    def step(self, eps, t, x):
+        t, dt = int(t), self.N // self.n
+        k = self.calls
+        self.calls += 1
+        if k == 1:   # the repeated timestep: average with the first prediction, restart from the first sample
+            return self._prev(self.first, t + dt, t, (eps + self.kept[-1]) / 2)
+        self.kept = (self.kept + [eps])[-4:]
+        e = self.kept
+        if k == 0:
+            self.first = x
+            comb = e[-1]
+        elif len(e) == 2:
+            comb = (3 * e[-1] - e[-2]) / 2
+        elif len(e) == 3:
+            comb = (23 * e[-1] - 16 * e[-2] + 5 * e[-3]) / 12
+        else:
+            comb = (55 * e[-1] - 59 * e[-2] + 37 * e[-3] - 9 * e[-4]) / 24
+        return self._prev(x, t, t - dt, comb)
+
+
+def denoise_loop(sd, cfg, latents, mask, masked_latents, ctx, num_steps, guidance_scale, unet=None, callback=None, sched=None):
     """The hot loop of RCDMsPipeline.__call__, src/pipelines/RCDMs_pipeline.py:455-503, generalised to
     S stories (the reference hard-codes batch 1 :408 and 64x64 :476):
       latents (S,4,f,H,W); mask (reps*S,1,f,H,W); masked_latents (reps*S,4,f,H,W); ctx (reps*S*f, L, D)
       with reps = 2 when guidance_scale > 1 (uncond block first)."""
     unet = unet or (lambda x, t, c: unet_forward(sd, cfg, x, t, c))
-    sched = DDIMOracle()
+    sched = sched or DDIMOracle()   # (sched: another oracle scheduler, e.g. PNDMOracle())
     sched.set_timesteps(num_steps)
     cfg_on = guidance_scale > 1.0
     x = latents * sched.init_noise_sigma

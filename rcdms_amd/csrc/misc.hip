@@ -138,6 +138,38 @@ __global__ void cfg_ddim_kernel(const f16* __restrict__ eps, int ld, float* lat,
   lat[idx] = k[2] * x0 + k[3] * e;
 }
 
+// Classifier-free guidance + one PLMS step of diffusers 0.24.0 PNDMScheduler (skip_prk_steps; step_plms + _get_prev_sample),
+// in place on lat; thread per latent element.  Row (*step) of `tab` (rcdms_amd/scheduler.py PNDMScheduler.plms_table):
+// (a, b, w_now, w1, w2, w3, slot_now, s1, s2, s3, mode, -):  e' = w_now e + w1 hist[s1] + w2 hist[s2] + w3 hist[s3];
+// x' = a x_src + b e' with x_src = the saved first sample in mode 2 (the repeated second call), x otherwise; mode 1 saves x;
+// slot_now >= 0 stores e.  hist: fp32 [5][total] — four prediction slots + the saved sample.
+__global__ void cfg_pndm_kernel(const f16* __restrict__ eps, int ld, float* lat, float* __restrict__ hist, int S, int reps, int F,
+                                int H, int W, float gs, const float* __restrict__ tab, const int* __restrict__ step) {
+  const size_t hw = (size_t)H * W, fhw = hw * F;
+  const size_t total = (size_t)S * 4 * fhw;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t rem = idx % fhw;
+  const size_t sc = idx / fhw;
+  const int c = (int)(sc & 3), s = (int)(sc >> 2);
+  float e = (float)eps[((size_t)s * fhw + rem) * ld + c];
+  if (reps == 2) {
+    const float ec = (float)eps[((size_t)(S + s) * fhw + rem) * ld + c];
+    e = e + gs * (ec - e);
+  }
+  const float* k = tab + (size_t)(*step) * 12;
+  const int slot = (int)k[6], mode = (int)k[10];
+  float mo = k[2] * e;
+  if (k[3] != 0.f) mo += k[3] * hist[(size_t)(int)k[7] * total + idx];
+  if (k[4] != 0.f) mo += k[4] * hist[(size_t)(int)k[8] * total + idx];
+  if (k[5] != 0.f) mo += k[5] * hist[(size_t)(int)k[9] * total + idx];
+  float x = lat[idx];
+  if (mode == 1) hist[4 * total + idx] = x;
+  if (mode == 2) x = hist[4 * total + idx];
+  if (slot >= 0) hist[(size_t)slot * total + idx] = e;
+  lat[idx] = k[0] * x + k[1] * mo;
+}
+
 // Stage-1 prior, per-step sequence assembly.  tok rows (b, l) <- the step-independent rows of `base`, except row
 // l == time_row of every sample, which takes the time embedding (one fp32 row, shared by the batch); x16 rows <-
 // the noisy embeddings in f16, sample b reading latent row b % n_lat (classifier-free guidance feeds the same 5
@@ -356,6 +388,16 @@ int rcdm_cfg_ddim_step(const void* eps, int32_t ld, float* latents, int32_t S, i
   const size_t total = (size_t)S * 4 * frames * H * W;
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const f16*)eps, ld, latents, S, reps, frames, H, W, guidance_scale, coef, step_counter);
+  return rcdm_check_launch();
+}
+
+int rcdm_cfg_pndm_step(const void* eps, int32_t ld, float* latents, float* history, int32_t S, int32_t reps, int32_t frames,
+                       int32_t H, int32_t W, float guidance_scale, const float* table, const int32_t* step_counter, void* stream) {
+  if (!eps || !latents || !history || !table || !step_counter) return RCDM_EINVAL;
+  if (S <= 0 || (reps != 1 && reps != 2) || frames <= 0 || H <= 0 || W <= 0 || ld < 4) return RCDM_EINVAL;
+  const size_t total = (size_t)S * 4 * frames * H * W;
+  hipLaunchKernelGGL(cfg_pndm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f16*)eps, ld, latents, history, S, reps, frames, H, W, guidance_scale, table, step_counter);
   return rcdm_check_launch();
 }
 

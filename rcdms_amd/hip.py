@@ -121,6 +121,7 @@ SYMBOLS = {
     "rcdm_ncfhw_to_rows": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "rcdm_rows_to_ncfhw": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "rcdm_cfg_ddim_step": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "rcdm_cfg_pndm_step": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
     "rcdm_prior_assemble": (C.c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rcdm_cfg_unclip_step": (C.c_int, [_P, _I, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P]),
     "rcdm_load_timestep": (C.c_int, [_P, _P, _P, _I, _P]),
@@ -358,6 +359,11 @@ def ncfhw_to_rows(x, b, Cc, frames, H, W, out, ld, c_pad, stream=None):
 def rows_to_ncfhw(rows, ld, b, Cc, frames, H, W, out, stream=None):
     _check(load().rcdm_rows_to_ncfhw(rows, ld, b, Cc, frames, H, W, out,
                                      stream_ptr() if stream is None else stream), "rcdm_rows_to_ncfhw")
+
+
+def cfg_pndm_step(eps, ld, lat, hist, S, reps, frames, H, W, gs, table, step, stream=None):
+    _check(load().rcdm_cfg_pndm_step(eps, ld, lat, hist, S, reps, frames, H, W, gs, table, step,
+                                     stream_ptr() if stream is None else stream), "rcdm_cfg_pndm_step")
 
 
 def cfg_ddim_step(eps, ld, lat, S, reps, frames, H, W, gs, coef, step, stream=None):

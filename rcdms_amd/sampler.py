@@ -26,7 +26,7 @@ class DenoiseLoop:
         dev = unet.device
         self.device = dev
         if not hasattr(scheduler, "alphas_cumprod"):
-            raise NotImplementedError(f"{type(scheduler).__name__}: only DDIM-family schedulers have a fused HIP step")
+            raise NotImplementedError(f"{type(scheduler).__name__}: only DDIM / PNDM schedulers have a fused HIP step")
         cfg = getattr(scheduler, "config", {})
         if getattr(cfg, "prediction_type", "epsilon") != "epsilon":
             raise NotImplementedError("only epsilon prediction")
@@ -35,18 +35,26 @@ class DenoiseLoop:
         if getattr(cfg, "clip_sample", False) or getattr(cfg, "thresholding", False):
             raise NotImplementedError("DenoiseLoop: clip_sample / thresholding are not built into the fused DDIM step "
                                       "(the reference pipeline sets clip_sample=False)")
-        scheduler.set_timesteps(self.T, device=None)
+        scheduler.set_timesteps(int(num_steps), device=None)
         ts = torch.as_tensor(scheduler.timesteps).to("cpu", torch.int64)
         self.timesteps = ts
-        ratio = int(cfg.get("num_train_timesteps", 1000)) // self.T
-        ac = torch.as_tensor(scheduler.alphas_cumprod).double().cpu()
-        final = torch.as_tensor(getattr(scheduler, "final_alpha_cumprod", 1.0)).double().cpu()
-        rows = []
-        for t in ts.tolist():
-            prev = t - ratio
-            a_t, a_p = ac[t], (ac[prev] if prev >= 0 else final)
-            rows.append([a_t.sqrt(), (1 - a_t).sqrt(), a_p.sqrt(), (1 - a_p).sqrt()])
-        self.coef = torch.tensor(rows, dtype=torch.float32).to(dev)
+        # PNDM (RCDMs_pipeline.py:72-79 accepts it; PLMS form): num_steps + 1 model evaluations, the multistep combination and
+        # the update in rcdm_cfg_pndm_step from the scheduler's own per-call table
+        self.pndm = hasattr(scheduler, "plms_table")
+        self.T = len(ts)
+        if self.pndm:
+            self.coef = scheduler.plms_table().to(dev)
+            self.hist = torch.zeros(5, stories * 4 * frames * height * width, dtype=torch.float32, device=dev)
+        else:
+            ratio = int(cfg.get("num_train_timesteps", 1000)) // self.T
+            ac = torch.as_tensor(scheduler.alphas_cumprod).double().cpu()
+            final = torch.as_tensor(getattr(scheduler, "final_alpha_cumprod", 1.0)).double().cpu()
+            rows = []
+            for t in ts.tolist():
+                prev = t - ratio
+                a_t, a_p = ac[t], (ac[prev] if prev >= 0 else final)
+                rows.append([a_t.sqrt(), (1 - a_t).sqrt(), a_p.sqrt(), (1 - a_p).sqrt()])
+            self.coef = torch.tensor(rows, dtype=torch.float32).to(dev)
         self.ts_dev = ts.to(torch.float32).to(dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.init_noise_sigma = float(getattr(scheduler, "init_noise_sigma", 1.0))
@@ -87,8 +95,7 @@ class DenoiseLoop:
                 ]
                 post = [
                     lambda: self.split.allgather(eps.ptr, self.eps_full.data_ptr(), nbytes),
-                    lambda: hip.cfg_ddim_step(self.eps_full.data_ptr(), eps.ld, self.lat.data_ptr(), S, R, f, H, W, self.gs,
-                                              self.coef.data_ptr(), self.step_dev.data_ptr()),
+                    lambda: self._sched_step(self.eps_full.data_ptr(), eps.ld),
                     lambda: hip.advance_step(self.step_dev.data_ptr()),
                 ]
             else:
@@ -102,13 +109,22 @@ class DenoiseLoop:
                                                p.x_in.ptr, p.x_in.ld, CIN_PAD),
                 ]
                 post = [
-                    lambda: hip.cfg_ddim_step(p.eps_out.ptr, p.eps_out.ld, self.lat.data_ptr(), S, R, f, H, W, self.gs,
-                                              self.coef.data_ptr(), self.step_dev.data_ptr()),
+                    lambda: self._sched_step(p.eps_out.ptr, p.eps_out.ld),
                     lambda: hip.advance_step(self.step_dev.data_ptr()),
                 ]
             v = self._variants[share] = dict(prog=p, pre=pre, post=post, graph=None)
         self.shared = share
         self._v = v
+
+    def _sched_step(self, eps_ptr, ld):
+        """CFG combine + scheduler.step (RCDMs_pipeline.py:492-497) on the device-resident latents, row `step` of the table."""
+        S, R, f, H, W = self.S, self.reps, self.f, self.H, self.W
+        if self.pndm:
+            hip.cfg_pndm_step(eps_ptr, ld, self.lat.data_ptr(), self.hist.data_ptr(), S, R, f, H, W, self.gs, self.coef.data_ptr(),
+                              self.step_dev.data_ptr())
+        else:
+            hip.cfg_ddim_step(eps_ptr, ld, self.lat.data_ptr(), S, R, f, H, W, self.gs, self.coef.data_ptr(),
+                              self.step_dev.data_ptr())
 
     def _cur(self):
         if self._v is None:   # a program is ~6 GB of packed weights and buffers: never build one as a side effect

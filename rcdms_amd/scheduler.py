@@ -1,4 +1,4 @@
-"""DDIM scheduler with the object protocol RCDMsPipeline expects from diffusers' DDIMScheduler
+"""DDIM (and PNDM / UnCLIP) schedulers with the object protocol RCDMsPipeline expects from diffusers' DDIMScheduler
 (reference: built at stage2_batchtest_rcdms_model.py:247 from configs/testing.yaml:18-21, mutated at
 src/pipelines/RCDMs_pipeline.py:84-109, used at :455-456,483,497).
 
@@ -105,6 +105,144 @@ class DDIMScheduler:
         if not return_dict:
             return (prev_sample,)
         return DDIMSchedulerOutput(prev_sample=prev_sample, pred_original_sample=x0)
+
+
+@dataclass
+class PNDMSchedulerOutput:
+    prev_sample: torch.Tensor
+
+
+class PNDMScheduler:
+    """PNDM / PLMS (the scheduler type RCDMsPipeline's constructor also accepts, src/pipelines/RCDMs_pipeline.py:72-79;
+    the class an SD-1.5 `scheduler/scheduler_config.json` names) with `skip_prk_steps=True`, the only mode Stable
+    Diffusion checkpoints configure.
+
+    Arithmetic of diffusers==0.24.0 `PNDMScheduler` (not vendored by the reference, not installed here: restated from
+    the published class — "parity unpinned", pinned by closed-form known-answer tests in tests/test_scheduler.py):
+      * "leading" spacing: _t = arange(n) * (N // n) + steps_offset; the PLMS list is [_t[:-1], _t[-2], _t[-1]] reversed,
+        i.e. n + 1 model evaluations with the second timestep repeated (981, 961, 961, 941, ... for n = 50, offset 1);
+      * step_plms: a linear multistep combination of the last <= 4 noise predictions (Adams-Bashforth weights
+        1 | 1/2,1/2 (the repeated call, restarting from the saved first sample) | 3/2,-1/2 | 23/12,-16/12,5/12 |
+        55/24,-59/24,37/24,-9/24), then
+        x' = sqrt(a'/a) x - (a' - a) e / (a sqrt(1 - a') + sqrt(a (1 - a) a'))            (`_get_prev_sample`).
+    `step()` is the host-visible torch form (stateful, like diffusers'); `plms_table()` gives the per-call rows the fused
+    rcdm_cfg_pndm_step kernel consumes (rcdms_amd/sampler.py)."""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 trained_betas=None, skip_prk_steps=False, set_alpha_to_one=False, prediction_type="epsilon",
+                 timestep_spacing="leading", steps_offset=0):
+        self._internal_dict = _FrozenDict(
+            num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+            beta_schedule=beta_schedule, trained_betas=trained_betas, skip_prk_steps=skip_prk_steps,
+            set_alpha_to_one=set_alpha_to_one, prediction_type=prediction_type, timestep_spacing=timestep_spacing,
+            steps_offset=steps_offset)
+        if prediction_type != "epsilon" or timestep_spacing != "leading":
+            raise NotImplementedError("only epsilon prediction with 'leading' spacing (the reference's configuration)")
+        if not skip_prk_steps:
+            raise NotImplementedError("PNDMScheduler: only skip_prk_steps=True (PLMS, what Stable Diffusion checkpoints "
+                                      "configure) is built; the Runge-Kutta warm-up steps are not")
+        if trained_betas is not None:
+            betas = torch.as_tensor(trained_betas, dtype=torch.float32)
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        elif beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        else:
+            raise NotImplementedError(f"{beta_schedule} is not implemented for {self.__class__}")
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.pndm_order = 4
+        self.num_inference_steps = None
+        self.timesteps = torch.arange(num_train_timesteps - 1, -1, -1, dtype=torch.int64)
+        self.ets, self.counter, self.cur_sample = [], 0, None
+
+    @property
+    def config(self):
+        return self._internal_dict
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        c = self.config
+        if num_inference_steps > c.num_train_timesteps:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                             f"`self.config.train_timesteps`: {c.num_train_timesteps}")
+        self.num_inference_steps = num_inference_steps
+        ratio = c.num_train_timesteps // num_inference_steps
+        t = torch.arange(num_inference_steps, dtype=torch.int64) * ratio + c.steps_offset
+        plms = torch.cat([t[:-1], t[-2:-1], t[-1:]]).flip(0).contiguous()
+        self.timesteps = plms.to(device) if device is not None else plms
+        self.ets, self.counter, self.cur_sample = [], 0, None
+
+    def _ab(self, timestep, prev_timestep):
+        """(sample coefficient, model-output coefficient) of `_get_prev_sample`, in fp64."""
+        ac = self.alphas_cumprod.double()
+        a_t = ac[timestep]
+        a_p = ac[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod.double()
+        denom = a_t * (1 - a_p).sqrt() + (a_t * (1 - a_t) * a_p).sqrt()
+        return float((a_p / a_t).sqrt()), float(-(a_p - a_t) / denom)
+
+    @staticmethod
+    def _weights(n_hist):
+        """Multistep weights over (newest, ..., oldest) for n_hist stored predictions."""
+        return {1: (1.0,), 2: (1.5, -0.5), 3: (23 / 12, -16 / 12, 5 / 12), 4: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}[n_hist]
+
+    def plms_table(self):
+        """fp32 [n_calls][12] for rcdm_cfg_pndm_step, one row per model evaluation of the current schedule:
+        (a, b, w_now, w1, w2, w3, slot_now (-1: this prediction is not stored), s1, s2, s3, mode, 0) with
+        x' = a x_src + b (w_now e + w1 hist[s1] + w2 hist[s2] + w3 hist[s3]); mode 1: also save x as the restart sample
+        (first call), mode 2: x_src is that saved sample (second call: the repeated timestep), else x_src = x."""
+        ratio = self.config.num_train_timesteps // self.num_inference_steps
+        rows, stored = [], []   # stored: ring slots of the kept predictions, oldest first
+        for i, t in enumerate(self.timesteps.tolist()):
+            if i == 1:
+                a, b = self._ab(t + ratio, t)
+                rows.append([a, b, 0.5, 0.5, 0.0, 0.0, -1, stored[-1], 0, 0, 2, 0])
+                continue
+            a, b = self._ab(t, t - ratio)
+            slot = i % 4 if i < 2 else (i - 1) % 4
+            prev = stored[-3:]
+            stored = prev + [slot]
+            w = self._weights(len(stored))
+            hist = list(reversed(prev))            # newest stored first
+            ws = list(w[1:]) + [0.0] * (3 - len(hist))
+            ss = hist + [0] * (3 - len(hist))
+            rows.append([a, b, w[0], ws[0], ws[1], ws[2], slot, ss[0], ss[1], ss[2], 1 if i == 0 else 0, 0])
+        return torch.tensor(rows, dtype=torch.float32)
+
+    def step(self, model_output, timestep, sample, return_dict=True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        ratio = self.config.num_train_timesteps // self.num_inference_steps
+        t = int(timestep)
+        prev_t = t - ratio
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_t = t
+            t = t + ratio
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            model_output = (model_output + self.ets[-1]) / 2
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(self.ets) == 2:
+            model_output = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            model_output = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+        a, b = self._ab(t, prev_t)
+        prev_sample = a * sample + b * model_output
+        self.counter += 1
+        return PNDMSchedulerOutput(prev_sample=prev_sample) if return_dict else (prev_sample,)
 
 
 @dataclass

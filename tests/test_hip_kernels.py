@@ -842,6 +842,39 @@ def test_layout_and_ddim(hiplib):
     assert int(step.item()) == 4
 
 
+def test_cfg_pndm_step_vs_scheduler(hiplib):
+    """rcdm_cfg_pndm_step replayed over a whole PLMS schedule (device step counter, prediction ring, saved first sample)
+    against the host-visible PNDMScheduler.step (diffusers 0.24.0 arithmetic restated; parity unpinned) and against the
+    oracle's independent PNDMOracle."""
+    from rcdms_amd import hip
+    from rcdms_amd.scheduler import PNDMScheduler
+    S, f, H, W, gs, n = 2, 5, 8, 8, 2.0, 9
+    g = torch.Generator().manual_seed(11)
+    sched = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1, skip_prk_steps=True)
+    sched.set_timesteps(n)
+    orc = O.PNDMOracle(beta_schedule="scaled_linear"); orc.set_timesteps(n)
+    assert torch.equal(sched.timesteps, orc.timesteps)
+    tab = sched.plms_table().to(DEV)
+    lat = torch.randn(S, 4, f, H, W, generator=g)
+    lat_d = lat.clone().to(DEV)
+    hist = torch.full((5, S * 4 * f * H * W), float("nan"), device=DEV)   # (no initialisation needed: NaN-filled)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    x, xo = lat.clone(), lat.clone()
+    for i, t in enumerate(sched.timesteps.tolist()):
+        eps = h16(torch.randn(2 * S, 4, f, H, W, generator=g))
+        rows = rows_from_5d(eps, 32)
+        hip.cfg_pndm_step(rows.data_ptr(), 32, lat_d.data_ptr(), hist.data_ptr(), S, 2, f, H, W, gs, tab.data_ptr(), step.data_ptr())
+        hip.advance_step(step.data_ptr())
+        torch.cuda.synchronize()
+        e_u, e_c = eps.chunk(2)
+        e = e_u + gs * (e_c - e_u)
+        x = sched.step(e, t, x).prev_sample
+        xo = orc.step(e, t, xo)
+        assert (lat_d.cpu() - x).abs().max() < 2e-5 * max(1.0, x.abs().max().item()), i
+        assert (x - xo).abs().max() < 2e-5 * max(1.0, x.abs().max().item()), i
+    assert int(step.item()) == n + 1
+
+
 def test_graph_capture_replay(hiplib):
     from rcdms_amd import hip
     M = N = K = 128

@@ -309,6 +309,31 @@ def test_denoise_loop_vs_oracle(hiplib, guidance):
     assert torch.equal(out, out2) and torch.equal(out, out3)
 
 
+def test_denoise_loop_pndm_vs_oracle(hiplib):
+    """The same loop with the other scheduler type the reference pipeline accepts (RCDMs_pipeline.py:72-79): PNDM / PLMS —
+    num_steps + 1 UNet evaluations, the multistep combination and the update in rcdm_cfg_pndm_step — against the oracle's
+    independent restatement (third-party arithmetic: parity unpinned)."""
+    from oracle import unet_oracle as O
+    from rcdms_amd.sampler import DenoiseLoop
+    from rcdms_amd.scheduler import PNDMScheduler
+    m = build("unet_tiny")
+    sd = synth.procedural_state_dict(shapes_of(mirrored("unet_tiny")), SEEDS["unet_tiny"])
+    cfg = O.tiny_config(width=64, cross_dim=64, layers_per_block=2)
+    s = _tiny_story(1)
+    sched = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, skip_prk_steps=True)
+    loop = DenoiseLoop(m, 1, 5, 16, 16, 13, 2.0, sched, 6)
+    loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+    seen = []
+    out = loop.run(callback=lambda i, t, lat: seen.append(t)).clone()
+    assert seen == [835, 669, 669, 503, 337, 171, 5]          # 1000 // 6 = 166, offset 1, the second timestep twice
+    with torch.no_grad():
+        ref = O.denoise_loop(sd, cfg, s["latents"], s["mask"], s["masked_latents"], s["ctx"], 6, 2.0, sched=O.PNDMOracle())
+    check(out, ref, 3.3e-3, 3e-3, "6-step PNDM loop")
+    loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+    out2 = loop.run(use_graph=False).clone()
+    assert torch.equal(out, out2)
+
+
 def test_story_batch_equals_single_stories(hiplib):
     """Stories are independent units: a batch of 2 stories == the two stories run alone, bit for bit
     per story?  Not bitwise (split-K / tile shapes depend on M), so within the block tolerance."""

@@ -42,6 +42,19 @@ def test_alias_and_ctor_mutates_scheduler_config():
     assert isinstance(RCDMsPipelineOutput(videos=torch.zeros(1)).videos, torch.Tensor)
 
 
+def test_ctor_accepts_pndm_and_forces_its_offset():
+    """The constructor's scheduler annotation (RCDMs_pipeline.py:72-79) includes PNDMScheduler; its steps_offset is forced
+    to 1 like DDIM's (:84-97), after which the PLMS timesteps are 981, 961, 961, ... for 50 steps."""
+    from rcdms_amd.scheduler import PNDMScheduler
+    sched = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True)
+    assert sched.config.steps_offset == 0
+    pipe = RCDMsPipeline(vae=None, text_encoder=None, tokenizer=None, unet=_FakeUNet(), local_module=_Tag(1.0),
+                         global_module=_Tag(2.0), scheduler=sched)
+    assert sched.config.steps_offset == 1 and pipe.scheduler is sched
+    sched.set_timesteps(50)
+    assert sched.timesteps[:3].tolist() == [981, 961, 961] and "eta" not in pipe.prepare_extra_step_kwargs(None, 0.0)
+
+
 def test_encode_mask_and_context_order_quirk():
     pipe, _ = make_pipe()
     mask = torch.zeros(5, 4, 4); mask[0] = 1.0                       # first frame seen
