@@ -78,7 +78,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 constexpr float MSUB_THR = 6.0f;
 
 template <int DS, int QF, bool PIPE, bool MASKED, int NW, int MD = 0>  // MD: MSUB with head dim MD (0: off); d padded to 16*DS for QK^T and to 32*DF for PV; a wave owns QF fragments of 32 queries
-__global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (MASKED && DS >= 5) ? 1 : 2) void flash_attn_kernel(const AttnArgs p) {   // (the masked wide-head forms need > 256 registers: one block per CU, the overflow in AGPRs instead of scratch)
   constexpr bool MSUB = MD > 0;
   static_assert(!MSUB || (PIPE && !MASKED && MD < 16 * DS), "MSUB: pipelined, unmasked kernel with a spare QK^T column only");
   constexpr int DF = (DS + 1) / 2;
@@ -446,15 +446,8 @@ int launch_flash(const AttnArgs& a_in, hipStream_t stream) {
   constexpr int DF = (DS + 1) / 2;
   constexpr int KP = 16 * DS + 8;
   const size_t lds = (size_t)2 * (KT * KP + KT * v_row_halfs(DF)) * sizeof(f16);  // ping-pong K and V images
-  static int nw_mode = -1;  // RCDM_ATTN_WAVES=4|8 forces the block size (A/B switch); default by shape
-  if (nw_mode < 0) {
-    const char* e = getenv("RCDM_ATTN_WAVES");
-    nw_mode = e ? atoi(e) : 0;
-  }
-  // 256-query blocks when there are enough of them to fill the chip and many key tiles to share
-  // measured (tools/kbench.py attn, RCDM_ATTN_WAVES=4|8): 256-query blocks are 3-30 % SLOWER on every shape (the K/V
-  // stream is not what binds; an 8-wave barrier per key tile costs more), so 8 is only ever taken when forced
-  const bool big = nw_mode == 8;
+  // (256-query, 8-wave blocks were measured 3-30 % SLOWER on every shape — the K/V stream is not what binds, an 8-wave barrier
+  // per key tile costs more — and are not instantiated any more)
   static int xcd_mode = -1;
   if (xcd_mode < 0) {
     const char* e = getenv("RCDM_ATTN_XCD");
@@ -465,9 +458,6 @@ int launch_flash(const AttnArgs& a_in, hipStream_t stream) {
   if (a.kvalid || a.causal) {
     dim3 grid(((a.Lq + 127) / 128) * a.heads * a.batch);
     hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), true, 4>), grid, dim3(256), lds, stream, a);
-  } else if (big) {
-    dim3 grid(((a.Lq + 255) / 256) * a.heads * a.batch);
-    hipLaunchKernelGGL((flash_attn_kernel<DS, 1, (DS <= 5), false, 8>), grid, dim3(512), lds, stream, a);
   } else {
     dim3 grid(((a.Lq + 127) / 128) * a.heads * a.batch);
     static int msub_mode = -1;  // RCDM_ATTN_MSUB=0: the fma-based softmax everywhere (A/B switch)

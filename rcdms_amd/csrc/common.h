@@ -120,26 +120,6 @@ __device__ __forceinline__ unsigned mix_f16_pack(unsigned r, float s, float t0, 
   return o;
 }
 
-// GEGLU behind a deferred LayerNorm (rcdm_gemm_lnx): the staged halfs are x W'^T of the RAW rows; (h * rstd - mr * S + b)
-__device__ __forceinline__ uint4 geglu8_lnx(uint4 h, uint4 g, const float (&bh)[8], const float (&bg)[8], const float (&sh)[8],
-                                            const float (&sg)[8], float rstd, float mr, float sc) {
-  union P { uint4 u; unsigned w[4]; f16 e[8]; } hh, gg, o;
-  hh.u = h;
-  gg.u = g;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const f32x2 hb = __builtin_elementwise_fma(splat2(-mr), f32x2{sh[2 * k], sh[2 * k + 1]}, f32x2{bh[2 * k], bh[2 * k + 1]});
-    const f32x2 gb = __builtin_elementwise_fma(splat2(-mr), f32x2{sg[2 * k], sg[2 * k + 1]}, f32x2{bg[2 * k], bg[2 * k + 1]});
-    // v_fma_mix_f32 converts the staged half on the fly: no separate v_cvt per element
-    const f32x2 hv = {mix_f16_f32(hh.w[k], 0, rstd, hb.x), mix_f16_f32(hh.w[k], 1, rstd, hb.y)};
-    const f32x2 gv = {mix_f16_f32(gg.w[k], 0, rstd, gb.x), mix_f16_f32(gg.w[k], 1, rstd, gb.y)};
-    const f32x2 r = hv * gelu2(gv) * splat2(sc);
-    o.e[2 * k] = (f16)r.x;
-    o.e[2 * k + 1] = (f16)r.y;
-  }
-  return o.u;
-}
-
 // sum over groups of LPR consecutive lanes (LPR a power of two, 8..64), result in every lane of the group: DPP steps
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: no LDS crossbar), ds_bpermute only across 16-lane rows
 template <int CTRL>

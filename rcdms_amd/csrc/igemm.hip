@@ -975,7 +975,7 @@ int pick_variant(const IgemmArgs& a) {
   const int nk = (a.Cin + BK - 1) / BK * (a.Ktot / a.Cin);
   if (a.Ktot != a.Cin) {
     if (a.N <= 64) return 5;  // conv_out (4 -> 8 channels): half the weight tile of 128x128 is padding (51 -> 28 us)
-    return (a.M >= 2560 && a.M <= 10240 && nk >= 120) ? 2 : 1;
+    return 1;   // (the 256x256 LDS-DMA tile's conv instantiation spills 48 B: only when forced; the ping-pong 256x256 tile covers its shapes)
   }
   const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
   if (t128 <= 64 && nk <= 24) return 4;  // (the two-slot 64x64 ring is 8-10 % faster back to back, tools/autotune.py, but +0.1 ms per step in the graph)
@@ -1009,7 +1009,10 @@ int plan_splits(int tiles, int slots, int nk, int requested) {
 }
 
 int fill_common(IgemmArgs& a, int requested_split, int* variant_out = nullptr) {
-  const int variant = pick_variant(a);
+  int variant = pick_variant(a);
+  // the 256x256 LDS-DMA tile is at the 256-register cap: its statistics / deferred-LayerNorm instantiations spilled (12 /
+  // 200 B of scratch) and are not built — such launches take the 128x128 tile, also when variant 2 is forced
+  if (variant == 2 && (a.stat_out || a.lnx_stat)) variant = 1;
   if (variant_out) *variant_out = variant;
   const TileCfg& tc = kTiles[variant];
   a.tilesM = (a.M + tc.bm - 1) / tc.bm;
@@ -1084,12 +1087,10 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
       RCDM_DEEP_LDS(128, 64, 3, LDS_128x64_3);
 #undef RCDM_DEEP_LDS
       set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, true, 1>, LDS_128);
-      set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2, true, 1>, LDS_256);
       set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2, true, 1>, LDS_64);
       set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4, true, 1>, LDS_64D);
       set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2, true, 1>, LDS_128x64);
       set_lds(igemm_dma_kernel<TAPS, 128, 128, 2, 2, 2, true, 2>, LDS_128);
-      set_lds(igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2, true, 2>, LDS_256);
       set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 2, true, 2>, LDS_64);
       set_lds(igemm_dma_kernel<TAPS, 64, 64, 2, 2, 4, true, 2>, LDS_64D);
       set_lds(igemm_dma_kernel<TAPS, 128, 64, 2, 2, 2, true, 2>, LDS_128x64);
@@ -1108,6 +1109,7 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
     return RCDM_ESHAPE;
   if ((a.stat_out || a.lnx_stat) && TAPS != 1) return RCDM_ESHAPE;
   if (a.lnx_stat && (a.splits > 1 || !a.lnx_S || a.lnx_parts < 1 || a.lnx_parts > kLnxMaxParts)) return RCDM_ESHAPE;
+  if (a.lnx_stat && variant == kFirstPP + 2) return RCDM_ESHAPE;   // the 256x256 ping-pong tile has no consumer epilogue (register cap); only reachable when that variant is forced
   if (variant == kVar16) {
     int rc = rcdm_igemm16_launch(a, TAPS, stream);
     if (rc) return rc;
@@ -1175,7 +1177,10 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   if (TAPS != 1 && variant >= kFirstDeep) variant = 5;
   switch (variant) {
     case 10: if constexpr (TAPS == 1) { RCDM_IGEMM_LAUNCH(128, 64, 2, 2, 3, 256, LDS_128x64_3); } break;
-    case 2: RCDM_IGEMM_LAUNCH(256, 256, 2, 4, 2, 512, LDS_256); break;
+    case 2:   // (no statistics / consumer instantiations of this tile: fill_common)
+      if (e16) hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2, true>), grid, dim3(512), LDS_256, stream, a);
+      else hipLaunchKernelGGL((igemm_dma_kernel<TAPS, 256, 256, 2, 4, 2, false>), grid, dim3(512), LDS_256, stream, a);
+      break;
     case 3: RCDM_IGEMM_LAUNCH(64, 64, 2, 2, 2, 256, LDS_64); break;
     case 4: RCDM_IGEMM_LAUNCH(64, 64, 2, 2, 4, 256, LDS_64D); break;
     case 5: RCDM_IGEMM_LAUNCH(128, 64, 2, 2, 2, 256, LDS_128x64); break;

@@ -140,6 +140,13 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // epilogue placement: the tables sit in the ring stage the LAST k-step does not read (stage nkl & 1), the f16 staging tile
+  // ([BM] rows of 2 BN + 16 bytes = 53760 B) clear of them: behind the tables when that is stage 0, in front when stage 1
+  constexpr int kStg = BM * (2 * BN + 16);
+  static_assert(lnx_table_bytes(BM, BN) <= 4096 && 4096 + kStg <= 2 * STAGE && kStg >= STAGE, "epilogue layout");
+  const bool lx_low = lx_on && !(nkl & 1);
+  float* const lx_tab = (float*)(smem + (lx_low ? 0 : kStg));
+  char* const stg = smem + (lx_low ? 4096 : 0);
   issue(0, 0);
   if (lx_on && t < BM) {
     float r_ = 1.f, m_ = 0.f;
@@ -178,6 +185,12 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
 #endif
     }
   }
+  // the ring stage the last k-step did not read is dead (read by nobody, filled by nobody): the deferred-LayerNorm tables go
+  // there NOW, so that the barrier below — which the epilogue needs anyway — publishes them (igemm_epilogue.h
+  // lnx_write_tables).  Not inside the loop: an ordinary global load anywhere in its body makes hipcc drain the LDS-DMA
+  // queue (vmcnt(0)) in front of every step's ds_reads (+0.3 ms per step, measured).
+  if constexpr (TAPS == 1 && !SLAB)
+    if (lx_on) lnx_write_tables<BM, BN>(p, lx_tab, cm0, cn0, t, lx_pre);
   wait_lgkm0();
   tick_barrier();  // every wave is done reading the ring: the LDS is free for the epilogue's staging tile
 #if RCDM_I16_ABLATE & 1
@@ -190,7 +203,8 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
     if (s == 1.2345678e33f) p.out[0] = (f16)s;
   }
 #else
-  tile_epilogue<FM, FN, SLAB, 256, BM, BN, false, TAPS == 1>(p, smem, acc, cm0, cn0, wm * (BM / 2), wn * (BN / 2), l15, kg, t, lx_pre, lx_on);
+  tile_epilogue<FM, FN, SLAB, 256, BM, BN, false, TAPS == 1 && !SLAB>(p, stg, acc, cm0, cn0, wm * (BM / 2), wn * (BN / 2), l15, kg, t,
+                                                                       lx_on ? lx_tab : nullptr);
 #endif
 }
 

@@ -357,7 +357,26 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
   }
   // every wave is past the last tick: no LDS read and no DMA is outstanding anywhere in the block
 
-  tile_epilogue<FMW, FNW, SLAB, 512, BM, BN, TAPS == 1, TAPS == 1, TAPS == 4>(p, smem, acc, cm0, cn0, grp * HM, wn * (BN / 4), l15, kg, t);
+  // deferred-LayerNorm consumer (only when this tile shape is forced: pick_variant keeps such launches off this kernel): the
+  // row / column tables behind the staging tile, one barrier, then the accumulators are transformed (igemm_epilogue.h)
+  constexpr bool kLX = TAPS == 1 && !SLAB && FMW < 8;   // (not on the 256x256 tile: at the 256-register cap already; rcdm_gemm_lnx refuses it there)
+  const float* ltab = nullptr;
+  if constexpr (kLX) {
+    if (p.lnx_stat != nullptr) {
+      f32x2 pre = {1.f, 0.f};
+      if (t < BM) {
+        float r_ = 1.f, m_ = 0.f;
+        lnx_row<1, kLnxMaxParts>(p.lnx_stat, p.lnx_ld, cm0 + t, cm0 + t < p.M, p.lnx_parts, 0, p.lnx_invC, p.lnx_eps, r_, m_);
+        pre = f32x2{r_, m_};
+      }
+      float* tab = (float*)(smem + BM * (2 * BN + 16));
+      lnx_write_tables<BM, BN>(p, tab, cm0, cn0, t, pre);
+      wait_lgkm0();
+      tick_barrier();
+      ltab = tab;
+    }
+  }
+  tile_epilogue<FMW, FNW, SLAB, 512, BM, BN, TAPS == 1, kLX, TAPS == 4>(p, smem, acc, cm0, cn0, grp * HM, wn * (BN / 4), l15, kg, t, ltab);
 }
 
 template <int FMW, int FNW>

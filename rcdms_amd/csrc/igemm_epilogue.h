@@ -8,15 +8,46 @@
 #include "igemm_args.h"
 #include "pp_sync.h"
 #ifndef RCDM_LNX_ABLATE
-#define RCDM_LNX_ABLATE 0   // debug builds (tools/lnx_bench.py): 1 = no partial-statistics loads, 2 = no S / bias vectors in the items, 4 = copy path
+#define RCDM_LNX_ABLATE 0   // debug builds (tools/lnx_bench.py): 1 = no partial-statistics loads
 #endif
 
 __device__ __forceinline__ void epi_store16(f16* dst, uint4 v) { *(uint4*)dst = v; }  // (non-temporal: measured, no change)
 
+// Deferred LayerNorm of the A rows (rcdm_gemm_lnx), table side.  Called by the kernel INSIDE its last k-step, after that
+// step's barrier, with `tab` in the ring stage the last step does not read (nobody reads or fills it any more): thread
+// t < BM publishes row t's (rstd, mean rstd) — lx_pre, summed from the partial statistics it requested at kernel start —
+// and threads t < BN / 4 the tile's per-column vectors: S, bias + row vector of the first sample the tile meets, bias + row
+// vector of the second.  The barrier that ends the k-loop makes them visible: no barrier of their own.
+// Layout behind tab: [BM][2] (rstd, mean rstd) | [BN] S | [BN] bias (+ row vector, first sample) | [BN] the same, second sample.
+template <int BM, int BN>
+__device__ __forceinline__ void lnx_write_tables(const IgemmArgs& p, float* tab, int cm0, int cn0, int t, f32x2 lx_pre) {
+  const bool lx_rvp = (p.epi & RCDM_EPI_ROWVEC) != 0 && p.rows_per_sample >= BM;   // the tile meets at most two samples
+  const int smp0 = lx_rvp ? cm0 / p.rows_per_sample : 0;
+  const int sw = lx_rvp ? (smp0 + 1) * p.rows_per_sample : 0x7fffffff;
+  const int vn = cn0 + 4 * t;
+  f32x4 vS = {0.f, 0.f, 0.f, 0.f}, vB = vS, vR0 = vS, vR1 = vS;
+  if (t < BN / 4 && vn < p.N) {
+    vS = *(const f32x4*)(p.lnx_S + vn);
+    if (p.epi & RCDM_EPI_BIAS) vB = *(const f32x4*)(p.bias + vn);
+    if (lx_rvp) {
+      vR0 = *(const f32x4*)(p.rowvec + (size_t)smp0 * p.ldt + vn);
+      if (sw < p.M && sw < cm0 + BM) vR1 = *(const f32x4*)(p.rowvec + (size_t)(smp0 + 1) * p.ldt + vn);
+    }
+  }
+  if (t < BM) *(f32x2*)(tab + 2 * t) = lx_pre;
+  if (t < BN / 4) {
+    *(f32x4*)(tab + 2 * BM + 4 * t) = vS;
+    *(f32x4*)(tab + 2 * BM + BN + 4 * t) = vB + vR0;
+    *(f32x4*)(tab + 2 * BM + 2 * BN + 4 * t) = vB + vR1;
+  }
+}
+constexpr int lnx_table_bytes(int BM, int BN) { return (2 * BM + 3 * BN) * 4; }
+
+// stg: where the f16 staging tile goes ([BM] rows of 2 BN + 16 bytes); ltab: the tables lnx_write_tables left (nullptr: none)
 template <int FMW, int FNW, bool SLAB, int NT, int BM, int BN, bool LN_OK = false, bool LX = false, bool PH = false>  // LX: rcdm_gemm_lnx consumer epilogues compiled in (GEMM launches only); PH: phase launch (bias-only epilogues, rows remapped)
-__device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f32x4 (&acc)[FNW][FMW], int cm0, int cn0,
-                                              int row0, int col0, int l15, int kg, int t,
-                                              f32x2 lx_pre = f32x2{1.f, 0.f}, bool lx_has_pre = false) {  // lx_pre: thread t's (rstd, mean rstd) of tile row t, summed by the caller
+__device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* stg, f32x4 (&acc)[FNW][FMW], int cm0, int cn0,
+                                              int row0, int col0, int l15, int kg, int t, const float* ltab = nullptr) {
+  char* const smem = stg;
 #if RCDM_PRIO_LOADS   // the epilogue's VALU work at raised priority against the co-resident block's MFMA runs
   __builtin_amdgcn_s_setprio(3);
 #endif
@@ -38,59 +69,22 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
     // ds_write_b64 group fall in 16 different bank pairs) -> coalesced 16-byte-per-lane pass with bias / per-sample row
     // vector / GELU / GEGLU / residual / scale in fp32
     constexpr int RS = 2 * BN + 16;
-    // deferred LayerNorm of the A rows (rcdm_gemm_lnx).  One thread per tile row sums the row's partial statistics and
-    // publishes (rstd, mean rstd) behind the staging tile; the per-column vectors of the tile — S, bias (+ the row vector
-    // of the at most two samples a tile meets) — go through LDS too (an item or a lane reads them as ds_read_b128, not as
-    // global loads).  Two forms: (a) lx_acc — epilogues without residual / GELU / GEGLU / scale (the q | k | v and attn2.to_q
-    // projections): rstd acc - (mean rstd) S + (bias + row vector) is applied to the ACCUMULATORS, before they are staged,
-    // and the staged halfs are copied out like a plain projection (the per-item epilogue costs this kernel +10 us on the
-    // 32x32-level q | k | v, the copy path nothing); (b) otherwise the items apply it (below).
-    const bool lnx = LX && p.lnx_stat != nullptr;
-    float* ltab = (float*)(smem + BM * RS);
-    float* lvS = ltab + 2 * BM;
-    float* lvB = lvS + BN;
-    float* lvB2 = lvB + BN;
-    const bool lx_rv = lnx && (p.epi & RCDM_EPI_ROWVEC) != 0;
-    const bool lx_rvp = lx_rv && p.rows_per_sample >= BM;     // the tile meets at most two samples: both rows staged
-    const int lx_smp0 = lx_rvp ? cm0 / p.rows_per_sample : 0;
-    const int lx_switch = lx_rvp ? (lx_smp0 + 1) * p.rows_per_sample : 0x7fffffff;
-    const bool lx_acc = lnx && !(p.epi & (RCDM_EPI_RESIDUAL | RCDM_EPI_GELU | RCDM_EPI_GEGLU)) && p.out_scale == 1.0f &&
-                        (!lx_rv || lx_rvp) && !(RCDM_LNX_ABLATE & 32);
-    // fast form of the plain items: out = f16(res sc + h (rstd sc) + ((bias + rv) sc - (mean rstd sc) S)) on v_fma_mix
-    const bool lx_fast = lnx && !lx_acc && !(p.epi & (RCDM_EPI_GELU | RCDM_EPI_GEGLU)) && (!lx_rv || lx_rvp);
-    const float lx_bsc = lx_fast ? p.out_scale : 1.0f;   // the staged bias vectors carry out_scale in the fast form
-    auto lx_tables = [&]() __attribute__((always_inline)) {
-      float rstd = 1.f, mr = 0.f;
-#if !(RCDM_LNX_ABLATE & 1)
-      if (lx_has_pre) {
-        rstd = lx_pre.x;
-        mr = lx_pre.y;
-      } else if (t < BM) {
-        lnx_row<1, kLnxMaxParts>(p.lnx_stat, p.lnx_ld, cm0 + t, cm0 + t < p.M, p.lnx_parts, 0, p.lnx_invC, p.lnx_eps, rstd, mr);
-      }
-#endif
-      const int vn = cn0 + 4 * t;
-      f32x4 vS = {0.f, 0.f, 0.f, 0.f}, vB = vS, vR0 = vS, vR1 = vS;
-      const bool vlive = t < BN / 4 && vn < p.N;
-      if (vlive) {
-        vS = *(const f32x4*)(p.lnx_S + vn);
-        if (p.epi & RCDM_EPI_BIAS) vB = *(const f32x4*)(p.bias + vn);
-        if (lx_rvp) {
-          vR0 = *(const f32x4*)(p.rowvec + (size_t)lx_smp0 * p.ldt + vn);
-          if (lx_switch < p.M && lx_switch < cm0 + BM) vR1 = *(const f32x4*)(p.rowvec + (size_t)(lx_smp0 + 1) * p.ldt + vn);
-        }
-      }
-      if (t < BM) *(f32x2*)(ltab + 2 * t) = f32x2{rstd, mr};
-      if (t < BN / 4) {
-        *(f32x4*)(lvS + 4 * t) = vS;
-        *(f32x4*)(lvB + 4 * t) = (vB + vR0) * lx_bsc;
-        *(f32x4*)(lvB2 + 4 * t) = (vB + vR1) * lx_bsc;
-      }
-    };
-    if constexpr (LX) if (lx_acc) {
-      lx_tables();
-      wait_lgkm0();
-      tick_barrier();
+    // deferred LayerNorm of the A rows (rcdm_gemm_lnx): LayerNorm(x) W^T + b = rstd (x W'^T) - (mean rstd) S + b'.  The identity
+    // is applied to the fp32 ACCUMULATORS, before anything is rounded — whatever the epilogue form: the staged halfs are then
+    // the normalised projection (+ bias + row vector), what the reference's fp16 Linear rounds, never the raw x W'^T whose
+    // magnitude grows with |mean S| (a raw row above 65504 would be inf) — and GEGLU / residual / scale run unchanged on top,
+    // with bias and row vector already in.  The tables come from lnx_write_tables (no barrier here: the k-loop's last one
+    // published them).
+    int epi = p.epi;
+    if constexpr (LX) if (ltab != nullptr) {
+      const float* lvS = ltab + 2 * BM;
+      const float* lvB = lvS + BN;
+      const float* lvB2 = lvB + BN;
+      const bool lx_rv = (p.epi & RCDM_EPI_ROWVEC) != 0;
+      const bool lx_rvp = lx_rv && p.rows_per_sample >= BM;     // both row vectors a tile can meet are in the tables
+      const int lx_switch = lx_rvp ? (cm0 / p.rows_per_sample + 1) * p.rows_per_sample : 0x7fffffff;
+      epi &= ~RCDM_EPI_BIAS;
+      if (lx_rvp) epi &= ~RCDM_EPI_ROWVEC;                      // (else the items add the row vector per row, as without lnx)
       f32x2 rsj[FMW];
       bool secj[FMW];
 #pragma unroll
@@ -122,7 +116,6 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
         *(uint2*)(smem + row * RS + col * 2) = pk.u;
       }
     }
-    if constexpr (LX) if (lnx && !lx_acc && !(RCDM_LNX_ABLATE & 16)) lx_tables();   // (after the staging writes: the accumulators are dead)
     wait_lgkm0();
     tick_barrier();
     const float sc = p.out_scale;
@@ -131,7 +124,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
 #else
     constexpr int U = 8;  // staged reads / residual loads in flight per thread (measured: 8 is 1-2 % faster than 4 on the 64x64 convs)
 #endif
-    if (p.epi & RCDM_EPI_GEGLU) {
+    if (epi & RCDM_EPI_GEGLU) {
       constexpr int CPR = BN / 16;  // output chunks (8 hidden columns) per row
       constexpr int ITEMS = BM * CPR;
       const int oc0 = geglu_out_col(cn0);
@@ -151,32 +144,11 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
           const int row = idx / CPR, c = idx - row * CPR;
           const int hc = (c >> 1) * 4 + (c & 1);
           const int m = cm0 + row, pn = cn0 + hc * 8;
-          if (LX && lnx) {
-            if (idx < ITEMS && m < p.M && pn < p.N) {
-              float bh[8], bg[8], sh[8], sg[8];
-              const float* lb = m >= lx_switch ? lvB2 : lvB;
-              const f32x4 a0 = *(const f32x4*)(lvS + hc * 8), a1 = *(const f32x4*)(lvS + hc * 8 + 4);
-              const f32x4 b0 = *(const f32x4*)(lvS + hc * 8 + kGegluGroup), b1 = *(const f32x4*)(lvS + hc * 8 + kGegluGroup + 4);
-              const f32x4 c0 = *(const f32x4*)(lb + hc * 8), c1 = *(const f32x4*)(lb + hc * 8 + 4);
-              const f32x4 d0 = *(const f32x4*)(lb + hc * 8 + kGegluGroup), d1 = *(const f32x4*)(lb + hc * 8 + kGegluGroup + 4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                sh[e] = a0[e]; sh[4 + e] = a1[e];
-                sg[e] = b0[e]; sg[4 + e] = b1[e];
-                bh[e] = c0[e]; bh[4 + e] = c1[e];
-                bg[e] = d0[e]; bg[4 + e] = d1[e];
-              }
-              const f32x2 rs = *(const f32x2*)(ltab + 2 * row);
-              Pack16 o;
-              o.u = geglu8_lnx(hh[u].u, gg[u].u, bh, bg, sh, sg, rs.x, rs.y, sc);
-              epi_store16(p.out + (size_t)m * p.ldc + oc0 + c * 8, o.u);
-              if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + oc0 + c * 8 + p.dup) = o.u;
-            }
-          } else if (idx < ITEMS && m < p.M && pn < p.N) {
+          if (idx < ITEMS && m < p.M && pn < p.N) {
             float bh[8], bg[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) bh[e] = bg[e] = 0.f;
-            if (p.epi & RCDM_EPI_BIAS) {
+            if (epi & RCDM_EPI_BIAS) {
               const f32x4 a0 = *(const f32x4*)(p.bias + pn), a1 = *(const f32x4*)(p.bias + pn + 4);
               const f32x4 b0 = *(const f32x4*)(p.bias + pn + kGegluGroup), b1 = *(const f32x4*)(p.bias + pn + kGegluGroup + 4);
 #pragma unroll
@@ -198,7 +170,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
     } else {
       constexpr int CPR = BN / 8;
       constexpr int ITEMS = BM * CPR;
-      const bool has_res = (p.epi & RCDM_EPI_RESIDUAL) != 0;
+      const bool has_res = (epi & RCDM_EPI_RESIDUAL) != 0;
       if constexpr (LN_OK && BN >= 320) {
         if (p.epi & kEpiLN) {
           // ---- rcdm_gemm_ln: the tile spans the whole output row (N <= BN).  Eight lanes share a row (five 16-byte chunks
@@ -293,7 +265,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
           return;
         }
       }
-      if (lx_acc || (p.epi == 0 && sc == 1.0f && !lnx)) {
+      if (epi == 0 && sc == 1.0f) {
         // plain projection (fused q/k/v): the staged halfs are the result; no conversion round trip
         for (int base = 0; base < ITEMS; base += NT * U) {
           uint4 hh[U];
@@ -340,53 +312,11 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
           const int idx = base + u * NT + t;
           const int row = idx / CPR, c8 = idx - row * CPR;
           const int m = cm0 + row, n = cn0 + c8 * 8;
-          if (LX && lx_fast) {
-#if RCDM_LNX_ABLATE & 8
-            if (idx < ITEMS && m < p.M && n < p.N) epi_store16(p.out + (size_t)m * p.ldc + n, hh[u].u);
-            continue;
-#endif
-            if (idx < ITEMS && m < p.M && n < p.N) {
-              const float* lb = m >= lx_switch ? lvB2 : lvB;
-#if RCDM_LNX_ABLATE & 2
-              const f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
-              (void)lb;
-#else
-              const f32x4 a0 = *(const f32x4*)(lvS + c8 * 8), a1 = *(const f32x4*)(lvS + c8 * 8 + 4);
-              const f32x4 b0 = *(const f32x4*)(lb + c8 * 8), b1 = *(const f32x4*)(lb + c8 * 8 + 4);
-#endif
-              const f32x2 rs = *(const f32x2*)(ltab + 2 * row);
-              const float s_eff = rs.x * sc, nmr = -rs.y * sc;
-              Pack16 o;
-#pragma unroll
-              for (int d = 0; d < 4; ++d) {
-                const float c0 = __builtin_fmaf(nmr, d < 2 ? a0[2 * (d & 1)] : a1[2 * (d & 1)], d < 2 ? b0[2 * (d & 1)] : b1[2 * (d & 1)]);
-                const float c1 = __builtin_fmaf(nmr, d < 2 ? a0[2 * (d & 1) + 1] : a1[2 * (d & 1) + 1],
-                                                d < 2 ? b0[2 * (d & 1) + 1] : b1[2 * (d & 1) + 1]);
-                if (has_res) {
-                  const float t0 = mix_f16_f32(hh[u].v[d], 0, s_eff, c0), t1 = mix_f16_f32(hh[u].v[d], 1, s_eff, c1);
-                  o.v[d] = mix_f16_pack(rr[u].v[d], sc, t0, t1);
-                } else {
-                  o.v[d] = mix_f16_pack(hh[u].v[d], s_eff, c0, c1);
-                }
-              }
-              epi_store16(p.out + (size_t)m * p.ldc + n, o.u);
-              if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + n + p.dup) = o.u;
-            }
-          } else if (idx < ITEMS && m < p.M && n < p.N) {
+          if (idx < ITEMS && m < p.M && n < p.N) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (float)hh[u].e[e];
-            if (LX && lnx) {   // rstd h - (mean rstd) S + (bias + row vector), the vectors out of LDS
-              const float* lb = m >= lx_switch ? lvB2 : lvB;
-              const f32x4 a0 = *(const f32x4*)(lvS + c8 * 8), a1 = *(const f32x4*)(lvS + c8 * 8 + 4);
-              const f32x4 b0 = *(const f32x4*)(lb + c8 * 8), b1 = *(const f32x4*)(lb + c8 * 8 + 4);
-              const f32x2 rs = *(const f32x2*)(ltab + 2 * row);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[e] = __builtin_fmaf(v[e], rs.x, __builtin_fmaf(-rs.y, a0[e], b0[e]));
-                v[4 + e] = __builtin_fmaf(v[4 + e], rs.x, __builtin_fmaf(-rs.y, a1[e], b1[e]));
-              }
-            } else if (p.epi & RCDM_EPI_BIAS) {
+            if (epi & RCDM_EPI_BIAS) {
               const f32x4 a0 = *(const f32x4*)(p.bias + n), a1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -394,7 +324,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
                 v[4 + e] += a1[e];
               }
             }
-            if ((p.epi & RCDM_EPI_ROWVEC) && !lx_rvp) {
+            if (epi & RCDM_EPI_ROWVEC) {
               const float* rv = p.rowvec + (size_t)(m / p.rows_per_sample) * p.ldt + n;
               const f32x4 a0 = *(const f32x4*)rv, a1 = *(const f32x4*)(rv + 4);
 #pragma unroll
@@ -403,7 +333,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* smem, f3
                 v[4 + e] += a1[e];
               }
             }
-            if (p.epi & RCDM_EPI_GELU) gelu8(v);
+            if (epi & RCDM_EPI_GELU) gelu8(v);
             Pack16 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[e] + (float)rr[u].e[e]) * sc);

@@ -3,7 +3,7 @@
 applies rstd (x W'^T) - rstd mean S + b' in its epilogue.  Reference (fp32 torch, the arithmetic of the reference's
 nn.LayerNorm + nn.Linear, attention.py:482-514 / motion_module.py:236-243 with PositionalEncoding :265-267):
     x = f16(A_p W_p^T + b_p + res);  y = epi(LayerNorm(x) (+ pe_f) W^T + b).
-Every tile shape (variants 1-10 as consumer, 1-5 and 10 as producer), plain / GEGLU / row-vector epilogues, ragged M, dup rows,
+Every tile shape (variants 1-10 as consumer — 8, the 256x256 ping-pong tile, refuses —, 1-5 and 10 as producer), plain / GEGLU / row-vector epilogues, ragged M, dup rows,
 rows whose mean is large against their spread (the cancellation case of E[x^2] - mean^2 and of the f16-staged x W'^T)."""
 import pytest
 import torch
@@ -127,6 +127,11 @@ def test_gemm_lnx_vs_reference(hiplib, M, C, N, form, shift, cvariant):
     hip.set_igemm_variant(cvariant)
     d = hip.GemmDesc(M, N, C, C, ldc, 0, epi, rps, N if form == "rowvec" else 0, 1.0, 1, 0)
     lx = hip.Lnx(0, 0, 0, stat.data_ptr(), parts, M, Sd.data_ptr(), 1e-5, C)
+    if cvariant == 8:   # the 256x256 ping-pong tile has no consumer epilogue: refused loudly, never computed wrongly
+        with pytest.raises(hip.RcdmError):
+            hip.gemm_lnx(d, lx, x.data_ptr(), Wd.data_ptr(), bias_d, rowvec_d, 0, out.data_ptr(), 0, 0)
+        hip.set_igemm_variant(-1)
+        return
     hip.gemm_lnx(d, lx, x.data_ptr(), Wd.data_ptr(), bias_d, rowvec_d, 0, out.data_ptr(), 0, 0)
     torch.cuda.synchronize()
     hip.set_igemm_variant(-1)
@@ -135,6 +140,60 @@ def test_gemm_lnx_vs_reference(hiplib, M, C, N, form, shift, cvariant):
     # against the LayerNorm -> Linear of the reference in fp32 (f16 storage of W and of the output are the only roundings
     # the separate-launch path has too; the deferred form adds the f16 staging of x W'^T before the mean term is removed)
     close(got, ref, rel=4e-3, abs_frac=6e-3)
+
+
+@pytest.mark.parametrize("cvariant", [-1, 1, 5, 9, 10])
+@pytest.mark.parametrize("form", ["plain", "geglu"])
+@pytest.mark.parametrize("mean,sigma", [(800.0, 8.0), (20000.0, 200.0)])
+def test_gemm_lnx_rows_far_from_zero(hiplib, mean, sigma, form, cvariant):
+    """Rows whose mean is 100x their spread, and rows of large magnitude: the raw projection x W'^T is then
+    ~ mean S[n] — thousands where the normalised result is O(1), and beyond the f16 range (65504) in the second case — so a
+    consumer that rounded it to f16 before removing the mean term would be off by ~2^-11 |mean S| rstd (0.1 and more) or
+    produce inf.  Every tile variant applies rstd acc - (mean rstd) S + b' to the fp32 accumulators; the tolerance below is
+    the ordinary one plus the cancellation of var = E[x^2] - mean^2 in fp32 at mean / sigma = 100 (1e4 x 2^-24 x a few)."""
+    from rcdms_amd import hip
+    M, C, N = 960, 640, 1920 if form == "plain" else 2560
+    g = torch.Generator().manual_seed(int(mean) + (form == "geglu"))
+    Kp = 64
+    Ap = h16(torch.randn(M, Kp, generator=g) * 0.01)
+    Wp = h16(torch.randn(C, Kp, generator=g) * Kp ** -0.5)
+    bp = torch.zeros(C)
+    sign = torch.where(torch.rand(M, 1, generator=g) < 0.5, -1.0, 1.0)
+    res = h16(sign * mean + sigma * torch.randn(M, C, generator=g))
+    x, stat, parts = _producer(hip, Ap, Wp, bp, res, M, C, Kp, -1)
+    xs = x.float().cpu()
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    W = torch.randn(N, C, generator=g) * C ** -0.5
+    bias = 0.1 * torch.randn(N, generator=g)
+    ln = torch.nn.functional.layer_norm(xs.double(), (C,), gamma.double(), beta.double(), 1e-5).float()
+    Wg, S, bf = _fold(W, gamma, beta, bias)
+    assert (xs.abs().max() * S.abs().max()).item() > (3e3 if mean < 1e4 else 65504), "the case must stress the raw projection"
+    if form == "geglu":
+        Wf32 = (W * gamma[None, :]).contiguous().to(DEV)
+        bf32 = bf.contiguous().to(DEV)
+        Wd = torch.empty(N, C, dtype=torch.float16, device=DEV)
+        bias_t = torch.empty(N, dtype=torch.float32, device=DEV)
+        hip.pack_geglu_rows(Wf32.data_ptr(), bf32.data_ptr(), N, C, Wd.data_ptr(), bias_t.data_ptr())
+        torch.cuda.synchronize()
+        Sd = Wd.float().sum(dim=1).contiguous()
+        epi, n_out = 1 | 8, N // 2
+        full = ln @ W.t() + bias
+        ref = full[:, :N // 2] * torch.nn.functional.gelu(full[:, N // 2:])
+    else:
+        Wd, Sd, bias_t = Wg.to(DEV), S.to(DEV), bf.to(DEV)
+        epi, n_out = 1, N
+        ref = ln @ h16(W).t() + bias
+    out = torch.full((M, n_out), float("nan"), dtype=torch.float16, device=DEV)
+    hip.set_igemm_variant(cvariant)
+    d = hip.GemmDesc(M, N, C, C, n_out, 0, epi, 1, 0, 1.0, 1, 0)
+    lx = hip.Lnx(0, 0, 0, stat.data_ptr(), parts, M, Sd.data_ptr(), 1e-5, C)
+    hip.gemm_lnx(d, lx, x.data_ptr(), Wd.data_ptr(), bias_t.data_ptr(), 0, 0, out.data_ptr(), 0, 0)
+    torch.cuda.synchronize()
+    hip.set_igemm_variant(-1)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all(), "inf / NaN: a raw x W'^T value left the f16 range before the mean term was removed"
+    close(got, ref, rel=8e-3, abs_frac=8e-3)
 
 
 def test_gemm_lnx_dup_rows_and_both_sides(hiplib):

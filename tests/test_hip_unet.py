@@ -325,7 +325,7 @@ def test_denoise_loop_pndm_vs_oracle(hiplib):
     loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
     seen = []
     out = loop.run(callback=lambda i, t, lat: seen.append(t)).clone()
-    assert seen == [835, 669, 669, 503, 337, 171, 5]          # 1000 // 6 = 166, offset 1, the second timestep twice
+    assert seen == [831, 665, 665, 499, 333, 167, 1]          # arange(6) * (1000 // 6) + 1, the second timestep twice
     with torch.no_grad():
         ref = O.denoise_loop(sd, cfg, s["latents"], s["mask"], s["masked_latents"], s["ctx"], 6, 2.0, sched=O.PNDMOracle())
     check(out, ref, 3.3e-3, 3e-3, "6-step PNDM loop")
