@@ -9,7 +9,7 @@ in HBM.  N > 1: one process per GPU (torch.distributed / RCCL), stories sharded 
 in the data path (stories are independent: SURVEY §8e) -> weak scaling; value = all ranks' frames / max-rank time.
 
 Prints ONE JSON line (rank 0).  `roofline`: bound = mfma; one "launch" = one replay of the captured step graph
-(~1.4k kernels = one UNet call + CFG/DDIM); achieved = 11.044 TFLOP algorithmic (SURVEY §8d, 2*MAC of the
+(~600 kernels = one UNet call + CFG/DDIM); achieved = 11.044 TFLOP algorithmic (SURVEY §8d, 2*MAC of the
 reference's conv/addmm/mm/bmm/baddbmm at b=2,f=5,64x64,L=85) x S / the average replay duration measured with HIP
 events on the launch stream.  The two CFG halves of a step have identical inputs up to the first cross-attention
 (RCDMs_pipeline.py:481-482), so conv_in, the first ResNet block and the first self-attention are evaluated once and

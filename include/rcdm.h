@@ -115,6 +115,10 @@ typedef struct {
   int32_t C;                  /* LayerNorm width = K of the consumer */
 } rcdm_lnx;
 int rcdm_gemm_stat_parts(const rcdm_gemm_desc* d);   /* 0: a statistics-producing launch of this shape is not available */
+/* Workspace an rcdm_gemm_lnx call of this shape needs, with the SAME tile / split decision the call itself takes (statistics
+ * producers and consumers are steered to other tile shapes than a plain rcdm_gemm of the shape: rcdm_gemm_workspace_bytes can
+ * disagree).  Non-zero means the shape would run split-K, which rcdm_gemm_lnx refuses on either side (RCDM_ESHAPE). */
+size_t rcdm_gemm_lnx_workspace_bytes(const rcdm_gemm_desc* d, int32_t producer, int32_t consumer);
 int rcdm_gemm_lnx(const rcdm_gemm_desc* d, const rcdm_lnx* x, const void* A, const void* W, const float* bias,
                   const float* rowvec, const void* residual, void* out, void* workspace, size_t workspace_bytes,
                   void* stream);
@@ -235,13 +239,17 @@ int rcdm_layernorm(const rcdm_layernorm_desc* d, const void* x, const float* gam
  *   context rows of that frame.  Q rows [batch*Lq][ldq] with head h at columns [h*d, (h+1)*d);
  *   K,V rows [batch*Lk][ldk|ldv]; out [batch*Lq][ldo].  d % 8 == 0, d <= 160.
  *   Range: scaled scores |scale * log2(e) * q.k| < 2^15 (the d = 40, Lk >= 256 kernel keeps its running max as an f16 inside
- *   the Q fragment and re-rounds Q * scale * log2(e) to f16: relative error ln2 * 2^-12 * |scaled score| on a probability;
- *   environment RCDM_ATTN_MSUB=0 selects the fp32-fma softmax instead, which has neither limit).
+ *   the Q fragment and re-rounds Q * scale * log2(e) to f16: relative error ln2 * 2^-12 * |scaled score| on a probability).
+ *   A caller that cannot bound its scores below that sets RCDM_ATTN_WIDE_RANGE in `flags` (or the environment sets
+ *   RCDM_ATTN_MSUB=0): the fp32-fma softmax kernel, which has neither limit.  rcdms_amd/engine.py sets it from a
+ *   data-independent bound on |q| |k| (LayerNorm output norm x Frobenius norms of the folded per-head weights).
  * ---------------------------------------------------------------------------------------------- */
+#define RCDM_ATTN_WIDE_RANGE 1
 typedef struct {
   int32_t batch, heads, Lq, Lk, d;
   int32_t ldq, ldk, ldv, ldo;
   float scale;
+  int32_t flags;              /* 0, or RCDM_ATTN_WIDE_RANGE */
 } rcdm_attn_desc;
 
 int rcdm_flash_attn(const rcdm_attn_desc* d, const void* Q, const void* K, const void* V, void* out,

@@ -33,6 +33,7 @@ struct AttnArgs {
   const unsigned char* kvalid;  // MASKED: [batch][Lk], 0 = key padded out (NULL = all valid)
   int causal;                   // MASKED: key k visible to query q only if k <= q
   int plain_order;              // RCDM_ATTN_XCD=0: blocks in plain (query block fastest) order, for A/B
+  int wide;                     // RCDM_ATTN_WIDE_RANGE: the caller cannot bound |scaled score| < 2^15 -> never the MSUB kernel
   long long* trace;             // -DRCDM_ATTN_TRACE builds (tools/trace_attn.py): per-wave s_memtime sums of the loop's phases
 };
 
@@ -468,7 +469,7 @@ int launch_flash(const AttnArgs& a_in, hipStream_t stream) {
     {
       // d = 40: a spare QK^T column (40 of 48), a V ones-row (row sums in fp32 out of the PV MFMA) and a long key loop
       if constexpr (DS == 3) {
-        if (msub_mode && a.d == 40 && a.Lk >= 4 * KT) {
+        if (msub_mode && !a.wide && a.d == 40 && a.Lk >= 4 * KT) {
           hipLaunchKernelGGL((flash_attn_kernel<DS, 1, true, false, 4, 40>), grid, dim3(256), lds, stream, a);
           return rcdm_check_launch();
         }
@@ -789,6 +790,7 @@ int rcdm_flash_attn_masked(const rcdm_attn_desc* d, const void* Q, const void* K
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
   a.c = d->scale * 1.4426950408889634f;
   a.kvalid = key_valid;
+  a.wide = (d->flags & RCDM_ATTN_WIDE_RANGE) != 0;
   a.causal = causal ? 1 : 0;
   a.trace = g_attn_trace;
   hipStream_t stream = (hipStream_t)stream_;

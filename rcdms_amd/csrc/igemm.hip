@@ -1316,6 +1316,16 @@ size_t rcdm_gemm_workspace_bytes(const rcdm_gemm_desc* d) {
   return a.splits > 1 ? (size_t)a.splits * a.M * a.N * sizeof(float) : 0;
 }
 
+size_t rcdm_gemm_lnx_workspace_bytes(const rcdm_gemm_desc* d, int32_t producer, int32_t consumer) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  IgemmArgs a{};
+  from_gemm(d, a);
+  if (producer) a.stat_out = (float*)16;      // any non-null value: the flags steer the tile choice, nothing is dereferenced
+  if (consumer) a.lnx_stat = (const float*)16;
+  fill_common(a, d->split_k);
+  return a.splits > 1 ? (size_t)a.splits * a.M * a.N * sizeof(float) : 0;
+}
+
 int rcdm_gemm(const rcdm_gemm_desc* d, const void* A, const void* W, const float* bias, const float* rowvec,
               const void* residual, void* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!d) return RCDM_EINVAL;

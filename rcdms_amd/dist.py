@@ -26,22 +26,41 @@ def split_stories(n_stories, world_size):
     return out
 
 
-def broadcast_module(module, src=0, bucket_bytes=256 << 20, wire_dtype=None):
+# State-dict keys whose tensors the launch planner rounds to f16 DIRECTLY (Packer.mat_f16 / conv3x3 / the chain packers) and
+# composes with nothing in fp32 first: for these f16(weight) on the wire is exactly what every rank's kernels consume.  All
+# other matrices are composed in fp32 before their single rounding — W diag(gamma) of the deferred LayerNorm (attn1 q|k|v,
+# attn2.to_q, ff.net.0.proj, the motion modules' q|k|v), W_proj_out W_ff2 (Packer.ffz), the tap sums of the phase-form
+# upsampler, W pe of the positional-encoding rows — and travel as stored, or a replica would round twice where the
+# single-GPU path rounds once.
+_F16_WIRE_SUFFIXES = ("conv1.weight", "conv2.weight", "conv_shortcut.weight", "downsamplers.0.conv.weight", "conv_in.weight",
+                      "conv_out.weight", "to_out.0.weight", "attn2.to_k.weight", "attn2.to_v.weight", "proj_in.weight",
+                      "time_emb_proj.weight", "time_embedding.linear_1.weight", "time_embedding.linear_2.weight")
+
+
+def f16_wire_ok(name):
+    return name.endswith(_F16_WIRE_SUFFIXES)
+
+
+def broadcast_module(module, src=0, bucket_bytes=256 << 20, wire_dtype=None, wire_ok=f16_wire_ok):
     """Broadcast every parameter and buffer of `module` from rank `src`, coalesced into flat buckets so that the
     ring over point-to-point xGMI links moves a few large messages instead of 1286 small ones.  ONE flat staging
-    buffer per dtype is allocated (bucket_bytes, or the largest single tensor) and reused by every bucket: tensors are
-    copied into it, broadcast, copied out — no per-bucket torch.cat allocation on any rank.
-    wire_dtype (e.g. torch.float16): floating tensors with >= 2 dims (the weight matrices, 99.9 % of the bytes) travel in
-    that dtype — half the bytes over xGMI for fp32 masters.  The kernels consume exactly f16(weight) (Packer.mat_f16), so
-    the launch plans built on every rank are bit-identical to rank `src`'s; `src` rounds its own masters the same way so
-    that all replicas' state dicts are equal too.  Vectors (biases, norm scales: consumed in fp32) always travel as stored."""
+    buffer per dtype is allocated (bucket_bytes, or the largest single tensor) and reused by every bucket: `src` copies
+    its tensors in, everybody copies the payload out — no per-bucket torch.cat allocation on any rank.
+    wire_dtype (e.g. torch.float16): the weight matrices the kernels consume as f16(weight) and nothing else
+    (`wire_ok(key)`: f16_wire_ok — the convolutions and the directly-rounded projections, ~60 % of the bytes) travel in that
+    dtype; `src` rounds its own masters of exactly those keys the same way, so all replicas' state dicts and launch plans
+    are bit-identical to the single-GPU path's.  Every other tensor (vectors, positional encodings, matrices that are
+    composed in fp32 before their one rounding) travels as stored."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    tensors = [t for t in module.state_dict().values() if torch.is_tensor(t)]
+    is_src = dist.get_rank() == src
     by_dtype = {}
-    for t in tensors:
+    for name, t in module.state_dict().items():
+        if not torch.is_tensor(t):
+            continue
         wire = t.dtype
-        if wire_dtype is not None and t.is_floating_point() and t.dim() >= 2 and t.element_size() > torch.empty(0, dtype=wire_dtype).element_size():
+        if (wire_dtype is not None and t.is_floating_point() and t.dim() >= 2 and wire_ok(name)
+                and t.element_size() > torch.empty(0, dtype=wire_dtype).element_size()):
             wire = wire_dtype
         by_dtype.setdefault((wire, t.device), []).append(t)
     for (wire, device), group in by_dtype.items():
@@ -68,8 +87,9 @@ def broadcast_module(module, src=0, bucket_bytes=256 << 20, wire_dtype=None):
             n = t.numel()
             if fill + n > cap:
                 flush()
-            with torch.no_grad():
-                flat[fill:fill + n].copy_(t.detach().reshape(-1))
+            if is_src:   # (receivers have nothing worth staging: their slice of `flat` is overwritten by the broadcast)
+                with torch.no_grad():
+                    flat[fill:fill + n].copy_(t.detach().reshape(-1))
             bucket.append(t)
             fill += n
             if fill * esz >= bucket_bytes:

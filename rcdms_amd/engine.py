@@ -13,9 +13,10 @@ X[(b f y x)][C] with an explicit row stride, so
 Weights are repacked once to f16 kernel layouts (fused [q;k;v], [k;v], GEGLU row interleave,
 conv3x3 tap-major); cross-attention K/V of the context are computed once per context, not per step.
 
-torch is used only for device memory, streams and host<->device copies.
+torch is used for device memory, streams, host<->device copies and the one-time pack-time weight algebra (folding a
+LayerNorm's gamma / beta into the matrix behind it, composing proj_out with the feed-forward's second Linear); nothing
+torch computes is on the per-step path.
 """
-import contextlib
 import math
 import os
 
@@ -69,8 +70,6 @@ class Plan:
         self.keep = []  # tensors that must outlive the plan (packed weights etc.)
         self.n_launch = 0
         self.op_weights = {}   # op index -> weight tensor of a GEMM / conv op (tools/prefetch_bound.py)
-        self._side = None      # second stream: ops emitted inside side_branch() run there (a parallel branch of the step graph)
-        self._in_side = False
 
     def scratch(self, name, nbytes):
         b = self.bufs.get(name)
@@ -102,40 +101,8 @@ class Plan:
     def add(self, fn, tag="misc"):
         if _DROP and tag.split()[0] in _DROP:   # timing experiments only (RCDM_DROP_OPS): the plan computes garbage
             return
-        if self._in_side:
-            side, inner = self._side, fn
-
-            def fn():
-                with torch.cuda.stream(side):
-                    inner()
         self.ops.append(fn)
         self.tags.append(tag)
-
-    @contextlib.contextmanager
-    def side_branch(self):
-        """Ops emitted inside run on the plan's side stream, ordered after everything emitted so far; join_side() orders
-        everything emitted after it behind them.  Captured, the two become a fork and a join of the step graph: an op that
-        nothing needs for a while (a ResNet's 1x1 shortcut) fills the ramps and tails of the launches of the main chain.
-        The side ops must not touch a buffer the main chain writes between the fork and the join.  Without RCDM_FORK=1: in line."""
-        if not FORK:
-            yield
-            return
-        assert not self._in_side
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        side, dev = self._side, self.device
-        self.add(lambda: side.wait_stream(torch.cuda.current_stream(dev)), "fork")
-        self._in_side = True
-        try:
-            yield
-        finally:
-            self._in_side = False
-
-    def join_side(self):
-        if not FORK:
-            return
-        side, dev = self._side, self.device
-        self.add(lambda: torch.cuda.current_stream(dev).wait_stream(side), "join")
 
     def run(self, ops=None):
         for op in (self.ops if ops is None else ops):
@@ -172,18 +139,31 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
         epi |= hip.EPI_GELU
     d = hip.GemmDesc(A.M, N, K, A.ld, out.ld, residual.ld if residual is not None else 0, epi,
                      rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k, dup_rows)
-    wsb = hip.gemm_workspace_bytes(d)
-    ws = plan.scratch("splitk_ws_side" if plan._in_side else "splitk_ws", max(wsb, 256))   # (a side branch runs beside the main chain's split-K launches)
-    bptr = bias.data_ptr() if bias is not None else 0
-    rv_t, rv_off = (rowvec[0], rowvec[1]) if rowvec else (None, 0)
     handle, x = None, None
-    if stat and LNX and not wsb and not geglu:
+    if stat and LNX and not geglu and not hip.gemm_lnx_workspace_bytes(d, producer=True, consumer=lnx is not None):
         parts = hip.gemm_stat_parts(d)
         if 0 < parts <= LNX_MAX_PARTS:
-            handle = _NS(buf=plan.scratch("rowstat", (A.M + dup_rows) * parts * 8), parts=parts, M=A.M, C=N, rows=A.M + dup_rows)
+            # the statistics of ALL producers live in one scratch buffer: a handle carries the generation it was written in,
+            # and a consumer checks that nothing has overwritten it since (emit order = execution order)
+            buf = plan.scratch("rowstat", (A.M + dup_rows) * parts * 8)
+            plan.rowstat_gen = getattr(plan, "rowstat_gen", 0) + 1
+            handle = _NS(buf=buf, parts=parts, M=A.M, C=N, rows=A.M + dup_rows, gen=plan.rowstat_gen)
+    # the workspace question is asked with the flags the launch will carry: a statistics producer / a consumer is steered
+    # to other tile shapes (and splits) than a plain GEMM of the same shape
+    if handle is not None or lnx is not None:
+        wsb = hip.gemm_lnx_workspace_bytes(d, producer=handle is not None, consumer=lnx is not None)
+    else:
+        wsb = hip.gemm_workspace_bytes(d)
+    ws = plan.scratch("splitk_ws", max(wsb, 256))
+    bptr = bias.data_ptr() if bias is not None else 0
+    rv_t, rv_off = (rowvec[0], rowvec[1]) if rowvec else (None, 0)
     if lnx is not None:
         assert not wsb, "deferred LayerNorm consumer cannot be a split-K launch (gemm_lnx_ok)"
         assert lnx[0].C == K and lnx[0].M >= A.M
+        # (a call that is consumer AND producer reads its rows' statistics at kernel start and writes the new ones in its
+        # epilogue, into the same buffer: legal only because both sides index it by the same rows of the same launch)
+        assert lnx[0].gen >= getattr(plan, "rowstat_gen", 0) - (1 if handle is not None else 0), \
+            "row statistics were overwritten by a later producer before this consumer was emitted"
     if handle is not None or lnx is not None:
         x = hip.Lnx(0, handle.parts if handle else 0, handle.rows if handle else 0, 0, lnx[0].parts if lnx else 0,
                     lnx[0].rows if lnx else 0, lnx[1].data_ptr() if lnx else 0, 1e-5, K)
@@ -203,20 +183,16 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
     if len(plan.ops) > n_before:
         plan.op_weights[len(plan.ops) - 1] = Wt
     plan.n_launch += 2 if wsb else 1
-    # a LayerNorm of exactly these output rows emitted NEXT can ride in this GEMM's epilogue (emit_layernorm)
-    plan.last_gemm = None
-    if len(plan.ops) == n_before:   # the op was left out (RCDM_DROP_OPS): nothing for a following LayerNorm to replace
+    if len(plan.ops) == n_before:   # the op was left out (RCDM_DROP_OPS)
         return None
-    if (LN_FUSE and N <= LN_FUSE_MAX_N and A.M >= LN_FUSE_MIN_M and not (geglu or gelu or rowvec) and split_k <= 1 and not wsb
-            and handle is None and lnx is None):
-        plan.last_gemm = dict(n_ops=len(plan.ops), d=d, A=A, Wt=Wt, bptr=bptr, residual=residual, out=out, N=N, K=K, epi=epi)
     return handle
 
 
 def gemm_lnx_ok(M, N, K, lda, ldc, geglu=False, dup_rows=0):
-    """Whether a deferred-LayerNorm consumer GEMM of this shape is a single launch (no split-K slabs)."""
+    """Whether a deferred-LayerNorm consumer GEMM of this shape is a single launch (no split-K slabs), asked the way the
+    launch itself decides (consumer flag set: rcdm_gemm_lnx_workspace_bytes)."""
     d = hip.GemmDesc(M, N, K, lda, ldc, 0, hip.EPI_GEGLU if geglu else 0, 1, 0, 1.0, 0, dup_rows)
-    return hip.gemm_workspace_bytes(d) == 0
+    return hip.gemm_lnx_workspace_bytes(d, consumer=True) == 0
 
 
 def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=None, rowvec=None, residual=None,
@@ -287,23 +263,6 @@ def emit_groupnorm_stats(plan, x, samples, rows_per_sample, gamma, beta, eps, gr
 
 
 def emit_layernorm(plan, x, gamma, beta, out, pe=None, rows_per_frame=1, frames=1):
-    lg = getattr(plan, "last_gemm", None)
-    plan.last_gemm = None
-    if (lg is not None and lg["n_ops"] == len(plan.ops) and lg["out"].ptr_key() == x.ptr_key() and lg["out"].M == x.M
-            and lg["N"] == x.C):
-        # the GEMM just emitted wrote exactly the rows this LayerNorm reads: one rcdm_gemm_ln instead of the two launches
-        plan.ops.pop()
-        plan.tags.pop()
-        g, ln = lg, hip.LnFuse(gamma.data_ptr(), beta.data_ptr(), pe.data_ptr() if pe is not None else 0, 0, out.ld,
-                               rows_per_frame, frames, 1e-5)
-
-        def fused():
-            ln.out = out.ptr
-            hip.gemm_ln(g["d"], ln, g["A"].ptr, g["Wt"].data_ptr(), g["bptr"],
-                        g["residual"].ptr if g["residual"] is not None else 0, g["out"].ptr)
-        plan.add(fused, f"gemm_ln M={x.M} N={g['N']} K={g['K']} epi={g['epi']} pe={int(pe is not None)}")
-        plan.keep += [gamma, beta, pe, ln]
-        return
     d = hip.LayerNormDesc(x.M, x.C, x.ld, out.ld, 1e-5, rows_per_frame, frames)
 
     def op():
@@ -313,8 +272,10 @@ def emit_layernorm(plan, x, gamma, beta, out, pe=None, rows_per_frame=1, frames=
     plan.n_launch += 1
 
 
-def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out):
-    d = hip.AttnDesc(batch, heads, Lq, Lk, d_head, q.ld, k.ld, v.ld, out.ld, d_head ** -0.5)
+def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out, wide=False):
+    """wide: the caller has no bound |scaled score| < 2^15 for this site (rcdm.h, rcdm_flash_attn): the fp32-argument softmax
+    kernel is used where the d = 40 kernel would take its softmax argument from the matrix pipe (attn_score_bound)."""
+    d = hip.AttnDesc(batch, heads, Lq, Lk, d_head, q.ld, k.ld, v.ld, out.ld, d_head ** -0.5, hip.ATTN_WIDE_RANGE if wide else 0)
 
     def op():
         hip.flash_attn(d, q.ptr, k.ptr, v.ptr, out.ptr)
@@ -322,12 +283,6 @@ def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out):
     plan.n_launch += 1
 
 
-# rcdm_gemm_ln (the LayerNorm that follows a token-matrix GEMM done in its epilogue): rows no wider than one 160x320 tile,
-# and enough of them to fill the chip with such tiles (256 CUs x 160).  OFF by default: measured 19.746 -> 19.728 ms per
-# step on one box (-0.1 %) — the fused launch (29.5 us) is one block per CU whose k-loop, residual read and two row stores
-# do not overlap, against 21-23 us + 11-13 us for the two well-overlapped launches it replaces.
-LN_FUSE = os.environ.get("RCDM_LN_FUSE", "0") != "0"
-LN_FUSE_MAX_N, LN_FUSE_MIN_M = 320, 20480
 # Deferred LayerNorm (rcdm_gemm_lnx) wherever the row-stationary chains are not used (the 32x32 / 16x16 / 8x8 levels): the
 # GEMM in front of a LayerNorm emits row statistics, the GEMM behind it takes the raw rows with gamma / beta folded into its
 # weights — no LayerNorm launch, no normalised tensor in HBM.  RCDM_LNX=0 keeps the stand-alone launches (same-process A/B).
@@ -336,10 +291,6 @@ LNX = os.environ.get("RCDM_LNX", "1") != "0"
 # the last C columns of a [M][5C] buffer whose first 4C columns the GEGLU projection fills, so one K = 5C GEMM replaces
 # ff.net.2 (+ residual) and proj_out (+ residual).  RCDM_FFZ=0: the two GEMMs (same-process A/B)
 FFZ = os.environ.get("RCDM_FFZ", "1") != "0"
-# parallel branches in the step graph (Plan.side_branch).  Off: measured +0.03 .. +0.15 ms per step with the fourteen ResNet
-# shortcuts on a side branch (a fork + join of a replayed hipGraph costs more than the ramps and tails the 1x1 GEMM fills,
-# wherever in the block the branch starts; profiles/r4_fork_ab.txt).  RCDM_FORK=1 turns it on (same results, bit for bit).
-FORK = os.environ.get("RCDM_FORK", "0") == "1"
 LNX_MAX_PARTS = 20
 XATTN_MAX_KEYS = 96   # rcdm_xattn: cross-attention with all scores of a query in registers
 
@@ -584,14 +535,41 @@ def pack_attention(pk, a, fused_self):
     return w
 
 
-def pack_basic_block(pk, b):
-    """BasicTransformerBlock parameters (attention.py:368-477); attn2 / norm2 are absent in the stage-1 prior's blocks."""
+MSUB_SCORE_LIMIT = 2.0 ** 15   # documented range of the matrix-pipe-softmax flash kernel (include/rcdm.h)
+
+
+def attn_score_bound(pk, a, ln, heads):
+    """Data-independent upper bound of |scale * log2(e) * q.k| over every input, for a self-attention behind a LayerNorm
+    (attention.py:482-493): ||LayerNorm(x) before gamma|| <= sqrt(C), so per head |q| <= sqrt(C) ||W_q,h diag(gamma)||_F +
+    ||W_q,h beta + b_q,h|| (Frobenius >= spectral norm), likewise |k|, and |q.k| <= |q| |k|.  inf when there is no
+    LayerNorm in front (nothing bounds the rows).  Evaluated once per block at pack time, in fp64."""
+    if ln is None or not pk.has(a + "to_q.weight"):
+        return float("inf")
+    gamma, beta = ln[0].double(), ln[1].double()
+    C = gamma.numel()
+    out = []
+    for n in "qk":
+        W = pk.sd[a + f"to_{n}.weight"].detach().to(gamma.device).double()
+        bias = pk.sd[a + f"to_{n}.bias"].detach().to(gamma.device).double() if pk.has(a + f"to_{n}.bias") else None
+        d = W.shape[0] // heads
+        Wh = (W * gamma[None, :]).reshape(heads, d, C)
+        off = (W @ beta + (bias if bias is not None else 0)).reshape(heads, d)
+        out.append(math.sqrt(C) * Wh.pow(2).sum(dim=(1, 2)).sqrt() + off.pow(2).sum(dim=1).sqrt())
+    d = pk.sd[a + "to_q.weight"].shape[0] // heads
+    return float((out[0] * out[1]).max().item() * d ** -0.5 * 1.4426950408889634)
+
+
+def pack_basic_block(pk, b, lnx=True):
+    """BasicTransformerBlock parameters (attention.py:368-477); attn2 / norm2 are absent in the stage-1 prior's blocks.
+    lnx=False: the deferred-LayerNorm operands (a second, gamma-folded f16 copy of q|k|v, attn2.to_q and the GEGLU
+    projection) are not packed — for blocks whose plan takes the row-stationary chains and never reads them."""
     C = pk.sd[b + "norm1.weight"].shape[0]
-    w = _NS(C=C, has_cross=pk.has(b + "attn2.to_q.weight"))
+    w = _NS(C=C, has_cross=pk.has(b + "attn2.to_q.weight"), pk=pk)
     w.ln = [(pk.vec(b + f"norm{i}.weight"), pk.vec(b + f"norm{i}.bias")) if pk.has(b + f"norm{i}.weight") else None
             for i in (1, 2, 3)]
     a1 = pack_attention(pk, b + "attn1.", True)
     w.qkv1, w.qkv1_b, w.o1, w.o1_b = a1.qkv, a1.qkv_b, a1.o, a1.o_b
+    w.attn1_ln, w.attn1_key = w.ln[0], b + "attn1."   # emit_basic_block: score bound of the self-attention (heads known there)
     if w.has_cross:
         a2 = pack_attention(pk, b + "attn2.", False)
         w.q2, w.q2_b, w.kv2, w.kv2_b, w.o2, w.o2_b = a2.q, a2.q_b, a2.kv, a2.kv_b, a2.o, a2.o_b
@@ -606,9 +584,9 @@ def pack_basic_block(pk, b):
     w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
     # deferred LayerNorm operands (rcdm_gemm_lnx): norm1 -> [q;k;v], norm2 -> attn2.to_q, norm3 -> GEGLU projection
     qkv_keys = tuple(b + f"attn1.to_{n}.weight" for n in "qkv")
-    w.lnx_qkv = pk.lnx_mat(qkv_keys, *w.ln[0], bias=w.qkv1_b) if w.ln[0] is not None else None
-    w.lnx_q2 = pk.lnx_mat((b + "attn2.to_q.weight",), *w.ln[1], bias=w.q2_b) if (w.has_cross and w.ln[1] is not None) else None
-    w.lnx_ff = pk.lnx_geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", *w.ln[2]) if (w.geglu and w.ln[2] is not None) else None
+    w.lnx_qkv = pk.lnx_mat(qkv_keys, *w.ln[0], bias=w.qkv1_b) if (lnx and w.ln[0] is not None) else None
+    w.lnx_q2 = pk.lnx_mat((b + "attn2.to_q.weight",), *w.ln[1], bias=w.q2_b) if (lnx and w.has_cross and w.ln[1] is not None) else None
+    w.lnx_ff = pk.lnx_geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", *w.ln[2]) if (lnx and w.geglu and w.ln[2] is not None) else None
     # row-stationary chains: attn1.to_out + res -> norm2 -> attn2.to_q, and attn2.to_out + res -> norm3 -> ff -> + res
     w.ch_in_qkv = w.ch_o1_q = w.ch_o2_ff = None
     if w.has_cross and w.geglu:
@@ -618,15 +596,17 @@ def pack_basic_block(pk, b):
     return w
 
 
-def pack_transformer(pk, p):
-    w = pack_basic_block(pk, p + "transformer_blocks.0.")
+def pack_transformer(pk, p, lnx=True, ffz=True):
+    """lnx / ffz False: the deferred-LayerNorm operands / the composed [W_po W_ff2 | W_po] matrix are left out (plans at or
+    above the chain kernels' row count never read them: UNetProgram passes what its geometry needs)."""
+    w = pack_basic_block(pk, p + "transformer_blocks.0.", lnx=lnx)
     b = p + "transformer_blocks.0.attn1."
     w.ch_in_qkv = pk.chain(p + "proj_in.weight", 3, wt_keys=(b + "to_q.weight", b + "to_k.weight", b + "to_v.weight"))
     w.gn_g, w.gn_b = pk.vec(p + "norm.weight"), pk.vec(p + "norm.bias")
     w.proj_in, w.proj_in_b = pk.mat_f16(p + "proj_in.weight"), pk.vec(p + "proj_in.bias")
     w.proj_out, w.proj_out_b = pk.mat_f16(p + "proj_out.weight"), pk.vec(p + "proj_out.bias")
     w.ffz = None
-    if w.geglu:
+    if w.geglu and ffz:
         t = p + "transformer_blocks.0."
         w.ffz = pk.ffz(t + "ff.net.2.weight", t + "ff.net.2.bias", p + "proj_out.weight", p + "proj_out.bias")
     # ... and the block's last chain with proj_out + the transformer's residual behind the feed-forward
@@ -638,7 +618,8 @@ def pack_transformer(pk, p):
     return w
 
 
-def pack_motion(pk, p, n_attn):
+def pack_motion(pk, p, n_attn, lnx=True):
+    """lnx=False: neither the deferred-LayerNorm operands nor the composed proj_out matrix (see pack_transformer)."""
     p = p + "temporal_transformer."
     C = pk.sd[p + "norm.weight"].shape[0]
     b = p + "transformer_blocks.0."
@@ -656,14 +637,14 @@ def pack_motion(pk, p, n_attn):
         w.attn.append(_NS(
             ln_g=ln_g, ln_b=ln_b, pe=pe,
             qkv=pk.mat_f16(a + "to_q.weight", a + "to_k.weight", a + "to_v.weight"),
-            lnx=pk.lnx_mat((a + "to_q.weight", a + "to_k.weight", a + "to_v.weight"), ln_g, ln_b, pe=pe),
+            lnx=pk.lnx_mat((a + "to_q.weight", a + "to_k.weight", a + "to_v.weight"), ln_g, ln_b, pe=pe) if lnx else None,
             o=pk.mat_f16(a + "to_out.0.weight"), o_b=pk.vec(a + "to_out.0.bias")))
     w.ff_ln = (pk.vec(b + "ff_norm.weight"), pk.vec(b + "ff_norm.bias"))
-    w.lnx_ff = pk.lnx_geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", *w.ff_ln)
+    w.lnx_ff = pk.lnx_geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", *w.ff_ln) if lnx else None
     w.ff1, w.ff1_b = pk.geglu(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias")
     w.ff2, w.ff2_b = pk.mat_f16(b + "ff.net.2.weight"), pk.vec(b + "ff.net.2.bias")
     w.ff_stream = pk.ff_stream(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", b + "ff.net.2.weight")
-    w.ffz = pk.ffz(b + "ff.net.2.weight", b + "ff.net.2.bias", p + "proj_out.weight", p + "proj_out.bias")
+    w.ffz = pk.ffz(b + "ff.net.2.weight", b + "ff.net.2.bias", p + "proj_out.weight", p + "proj_out.bias") if lnx else None
     # row-stationary chains: proj_in -> norms[0] + pe -> qkv;  to_out + res -> norms[1] + pe -> qkv;  to_out + res ->
     # ff_norm -> ff -> + res
     w.chains = w.chain_ffz = None
@@ -699,10 +680,9 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
     = this block's slice of the batched time_emb_proj(silu(emb)) table.  x may be a concat view."""
     g = geo
     res = x
-    if w.shortcut is not None:   # needs only x and is needed only by conv2: a parallel branch of the step graph
+    if w.shortcut is not None:
         res = plan.rows("res_sc", g.M, w.cout)
-        with plan.side_branch():
-            emit_gemm(plan, x, w.shortcut, w.cout, w.cin, res, bias=w.sb)
+        emit_gemm(plan, x, w.shortcut, w.cout, w.cin, res, bias=w.sb)
     a1 = plan.rows("norm", g.M, x.C)
     emit_groupnorm(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, True, a1, groups)
     h1 = plan.rows("res_h1", g.M, w.cout)
@@ -710,8 +690,6 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
                  rowvec=(temb[0], temb[1], temb[2], g.f * g.hw))
     a2 = plan.rows("norm", g.M, w.cout)
     emit_groupnorm(plan, h1, g.b, g.f * g.hw, w.g2, w.b2, eps, True, a2, groups)
-    if w.shortcut is not None:
-        plan.join_side()
     emit_conv3x3(plan, a2, g.n_img, g.H, g.W, w.conv2, w.cout, w.cout, out, bias=w.cb2, residual=res, scale=out_scale,
                  dup_rows=dup_rows)
 
@@ -782,7 +760,6 @@ def emit_rowchain(plan, a_in, res, tok, a_bias, ln, pe, stream, tail, out, rows_
     plan.add(op, f"rowchain M={M} C={C} tail={tail} res={int(res is not None)} pe={int(pe is not None)} gn={int(gn is not None)}")
     plan.keep += [a_bias, ln[0], ln[1], pe, ws, b1p, b2, z[1] if z else None]
     plan.n_launch += 1
-    plan.last_gemm = None
 
 
 def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None, tok_stat=None, lnx=None, z=None):
@@ -812,7 +789,6 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None,
         plan.add(op, f"ff_fused M={M} C={C}")
         plan.keep += [ln_g, ln_b, ws, b1p, ff2_b]
         plan.n_launch += 1
-        plan.last_gemm = None
         return
     gg = plan.rows("geglu", M, 4 * C)
     if tok_stat is not None and lnx is not None and gemm_lnx_ok(M, 8 * C, C, tok.ld, gg.ld, geglu=True):
@@ -849,7 +825,10 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
     else:
         emit_layernorm(plan, tok.rows(0, Ms), w.ln[0][0], w.ln[0][1], a.rows(0, Ms))
         emit_gemm(plan, a.rows(0, Ms), w.qkv1, 3 * C, C, qkv, bias=w.qkv1_b)
-    emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), ns, heads, Lq, Lq, d_head, ao.rows(0, Ms))
+    if not hasattr(w, "score_bound"):
+        w.score_bound = attn_score_bound(w.pk, w.attn1_key, w.attn1_ln, heads)
+    emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), ns, heads, Lq, Lq, d_head, ao.rows(0, Ms),
+                    wide=w.score_bound >= MSUB_SCORE_LIMIT)
     chain_q = w.has_cross and w.ch_o1_q is not None and not shared_half and big
     # (below CHAIN_MIN_ROWS only: with more rows the N = C producers run on the ping-pong kernel, which has no statistics
     # epilogue — the b = 8 configuration measured 59.5 ms per step without and 60.0 with the deferred form at 40960 rows)
@@ -1128,14 +1107,15 @@ class UNetProgram:
         site = [0]
 
         def transformer(p, x, geo, out, shared_half=False):
-            w = pack_transformer(pk, p)
+            small = geo.M < CHAIN_MIN_ROWS   # below the chain kernels' row count: deferred LayerNorms + composed proj_out
+            w = pack_transformer(pk, p, lnx=small or shared_half, ffz=small)
             kv = plan.rows(f"ctx_kv{site[0]}", geo.n_img * L, 2 * w.C, unique=True)
             site[0] += 1
             img = emit_ctx_kv(ctx_plan, w, self.ctx16, kv, geo.n_img, L, heads)
             emit_transformer(plan, w, x, geo, kv, L, heads, out, groups, shared_half=shared_half, ctx_img=img)
 
         def motion(p, x, geo, out):
-            emit_motion(plan, pack_motion(pk, p, n_attn), x, geo, mheads, out, groups)
+            emit_motion(plan, pack_motion(pk, p, n_attn, lnx=geo.M < CHAIN_MIN_ROWS), x, geo, mheads, out, groups)
 
         def layer(pb, j, kind_attn, res, x, geo, final_out, shared=False):
             """resnet -> [transformer] -> [motion]; the LAST op writes final_out, the others ping-pong.
@@ -1392,7 +1372,7 @@ def run_tokens(kind, sd, x, ctx=None, heads=8):
             qkv = plan.rows("qkv", M, 3 * inner)
             emit_gemm(plan, tok, w.qkv, 3 * inner, C, qkv, bias=w.qkv_b)
             emit_flash_attn(plan, qkv.cols(0, inner), qkv.cols(inner, inner), qkv.cols(2 * inner, inner), B, heads, Lq, Lq,
-                            d_head, ao)
+                            d_head, ao, wide=True)   # (a bare CrossAttention.forward: no LayerNorm in front bounds its rows)
         else:
             w = pack_attention(pk, "", False)
             q = plan.rows("qkv", M, inner)

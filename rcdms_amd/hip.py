@@ -69,7 +69,10 @@ class RowChainDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("heads", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
                 ("d", C.c_int32), ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32),
-                ("ldo", C.c_int32), ("scale", C.c_float)]
+                ("ldo", C.c_int32), ("scale", C.c_float), ("flags", C.c_int32)]
+
+
+ATTN_WIDE_RANGE = 1   # AttnDesc.flags: scores not bounded below 2^15 -> never the matrix-pipe-softmax (MSUB) kernel
 
 
 class TemporalAttnDesc(C.Structure):
@@ -86,6 +89,7 @@ SYMBOLS = {
     "rcdm_last_hip_error_string": (C.c_char_p, []),
     "rcdm_gemm_ln": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(LnFuse), _P, _P, _P, _P, _P, _P]),
     "rcdm_gemm_stat_parts": (C.c_int, [C.POINTER(GemmDesc)]),
+    "rcdm_gemm_lnx_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc), _I, _I]),
     "rcdm_set_groupnorm_fold": (C.c_int, [_I]),
     "rcdm_gemm_lnx": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(Lnx), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_gemm_workspace_bytes": (_SZ, [C.POINTER(GemmDesc)]),
@@ -263,6 +267,10 @@ def set_groupnorm_fold(on):
 
 def gemm_stat_parts(desc):
     return int(load().rcdm_gemm_stat_parts(C.byref(desc)))
+
+
+def gemm_lnx_workspace_bytes(desc, producer=False, consumer=False):
+    return int(load().rcdm_gemm_lnx_workspace_bytes(C.byref(desc), int(bool(producer)), int(bool(consumer))))
 
 
 def gemm_lnx(desc, lnx, a, w, bias, rowvec, residual, out, workspace, workspace_bytes, stream=None):

@@ -124,10 +124,17 @@ def _unet_worker(rank, world, port, q):
         sd = m.state_dict()
         digest = torch.cat([t.reshape(-1).double() for t in sd.values()]).sum().item()
         ok_round = True
-        if rank == 0:    # src holds f16-rounded matrices and untouched vectors afterwards
+        if rank == 0:    # src holds f16-rounded copies of the DIRECTLY rounded matrices only (dist.f16_wire_ok: convs, to_out,
+            from rcdms_amd.dist import f16_wire_ok   # attn2 k / v, proj_in, time embeddings); everything the planner composes in
+            n_f16 = 0                                # fp32 first (q | k | v, ff, proj_out, upsamplers, pe) and every vector is untouched
             for k, v in sd.items():
-                want = before[k].half().float() if before[k].dim() >= 2 else before[k]
-                ok_round &= torch.equal(v, want)
+                f16 = world == 2 and before[k].dim() >= 2 and f16_wire_ok(k)
+                n_f16 += f16
+                ok_round &= torch.equal(v, before[k].half().float() if f16 else before[k])
+            ok_round &= (n_f16 > 100) == (world == 2)
+            ok_round &= not f16_wire_ok("down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.weight")
+            ok_round &= not f16_wire_ok("up_blocks.1.motion_modules.0.temporal_transformer.transformer_blocks.0.attention_blocks.0.pos_encoder.pe")
+            ok_round &= f16_wire_ok("mid_block.resnets.0.conv1.weight")
         q.put((rank, n_keys, digest, m._programs == {}, ok_round))
     finally:
         dist.destroy_process_group()

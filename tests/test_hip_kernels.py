@@ -750,6 +750,35 @@ def test_flash_attn_msub_large_logits(hiplib, gain):
     close(got, ref, rel=2e-3, abs_frac=4e-3 if gain <= 6 else 4e-2)
 
 
+def test_flash_attn_wide_range_flag(hiplib):
+    """RCDM_ATTN_WIDE_RANGE (what rcdms_amd.engine sets when its weight-norm bound of a site's scores reaches 2^15): the
+    d = 40 launch takes the fp32-argument softmax kernel, whose error does not grow with the score magnitude.  Scores of
+    ~1300 here: with the flag the result is at the ordinary tolerance, where the matrix-pipe-softmax kernel needs 10x that
+    (test_flash_attn_msub_large_logits)."""
+    from rcdms_amd import hip
+    L, heads, d, gain = 1024, 2, 40, 30.0
+    C = heads * d
+    g = torch.Generator().manual_seed(77)
+    q = h16(torch.randn(1, L, C, generator=g) * gain ** 0.5)
+    k = h16(torch.randn(1, L, C, generator=g) * gain ** 0.5)
+    v = h16(torch.randn(1, L, C, generator=g))
+    ref = O.attention_core(q, k, v, heads)
+    qd, kd, vd = (t.reshape(-1, C).half().to(DEV) for t in (q, k, v))
+    errs = []
+    for flags in (0, hip.ATTN_WIDE_RANGE):
+        out = torch.full((L, C), float("nan"), dtype=torch.float16, device=DEV)
+        desc = hip.AttnDesc(1, heads, L, L, d, C, C, C, C, d ** -0.5, flags)
+        hip.flash_attn(desc, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        got = out.float().cpu().reshape(1, L, C)
+        assert torch.isfinite(got).all()
+        errs.append((got - ref).abs().max().item())
+        if flags:
+            close(got, ref, rel=2e-3, abs_frac=4e-3)
+    print(f"|scaled score| ~1300: max abs err {errs[0]:.3e} (matrix-pipe softmax argument) vs {errs[1]:.3e} (RCDM_ATTN_WIDE_RANGE)")
+    assert errs[1] < errs[0]
+
+
 @pytest.mark.parametrize("b,frames,pixels,heads,d", [(2, 5, 64, 8, 40), (1, 5, 16, 8, 160), (2, 5, 33, 8, 8), (1, 3, 20, 4, 16)])
 def test_temporal_attn(hiplib, b, frames, pixels, heads, d):
     from rcdms_amd import hip
