@@ -206,6 +206,29 @@ size_t rcdm_groupnorm_workspace_bytes(const rcdm_groupnorm_desc* d);
 int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float* gamma,
                         const float* beta, void* y, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* A split-K GEMM / conv whose reduce pass ALSO leaves the partial statistics of the GroupNorm that reads its output next —
+ * resnet.py:185-202 (conv1 -> norm2), attention.py:328 / motion_module.py:162 (the norm in front of a transformer / motion
+ * module, fed by conv2 or by the feed-forward GEMM) — so that the norm needs no statistics launch and no extra read of the
+ * tensor:  rcdm_gemm_gnstat / rcdm_conv3x3_gnstat(d, gn, ..., gn_workspace)  then  rcdm_groupnorm_silu_prestat(gn, out, ...,
+ * gn_workspace).  `gn` describes the norm over exactly the rows the launch writes (samples * rows_per_sample == M, C == N,
+ * ldx == ldc).  The statistics are taken from the STORED halfs in the order of the stand-alone pass: results are bit-identical
+ * to rcdm_gemm / rcdm_conv3x3 followed by rcdm_groupnorm_silu.  *_gnstat_ok: 1 when the pair qualifies (the launch is split-K
+ * — only then does a reduce pass exist —, no GEGLU / dup_rows / upsample == 2, the norm takes its three-launch form); the
+ * calls return RCDM_ESHAPE otherwise.  gn_workspace: rcdm_groupnorm_workspace_bytes(gn), the same bytes passed on. */
+int rcdm_gemm_gnstat_ok(const rcdm_gemm_desc* d, const rcdm_groupnorm_desc* gn);
+int rcdm_gemm_gnstat(const rcdm_gemm_desc* d, const rcdm_groupnorm_desc* gn, const void* A, const void* W, const float* bias,
+                     const float* rowvec, const void* residual, void* out, void* workspace, size_t workspace_bytes,
+                     void* gn_workspace, size_t gn_workspace_bytes, void* stream);
+int rcdm_conv3x3_gnstat_ok(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn);
+int rcdm_conv3x3_gnstat(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn, const void* in, const void* W,
+                        const float* bias, const float* rowvec, const void* residual, void* out, void* workspace,
+                        size_t workspace_bytes, void* gn_workspace, size_t gn_workspace_bytes, void* stream);
+/* finalize + apply only: the partial statistics are already in `workspace` (left there by a *_gnstat call with this
+ * descriptor).  rcdm_groupnorm_prestat_ok: 1 when this descriptor's norm has a statistics pass to replace (three-launch
+ * form; the smallest tensors run as one launch). */
+int rcdm_groupnorm_prestat_ok(const rcdm_groupnorm_desc* d);
+int rcdm_groupnorm_silu_prestat(const rcdm_groupnorm_desc* d, const void* x, const float* gamma, const float* beta, void* y,
+                                void* workspace, size_t workspace_bytes, void* stream);
 /* tuning / test switch: 1 = norms with >= 4 samples and <= 128 partial blocks per sample (the per-frame norms of the
  * transformers / motion modules) run as TWO launches — statistics, then an apply kernel whose blocks finalise their sample's
  * groups themselves (bit-identical to the three-launch form) — 0 = always statistics / finalize / apply, -1 = default

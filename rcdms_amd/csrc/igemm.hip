@@ -29,6 +29,7 @@
 #include <string.h>
 #include "common.h"
 #include "igemm_args.h"
+#include "gn_plan.h"
 #ifndef RCDM_LNX_ABLATE
 #define RCDM_LNX_ABLATE 0   // debug builds (tools/lnx_bench.py): 1 = no partial-statistics loads, 64 = no accumulator transform, 128 = no table write, 256 = no producer statistics
 #endif
@@ -43,7 +44,7 @@ __device__ __forceinline__ void load8(const float* src, float (&d)[8]) {
   d[4] = b[0]; d[5] = b[1]; d[6] = b[2]; d[7] = b[3];
 }
 
-__device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n, float (&v)[8], float (&g)[8]) {
+__device__ __forceinline__ uint4 epilogue_store(const IgemmArgs& p, int m, int n, float (&v)[8], float (&g)[8]) {   // returns the 8 halfs it stored
   int oc = n;
   if (p.epi & RCDM_EPI_GEGLU) {
     if (p.epi & RCDM_EPI_BIAS) {
@@ -84,6 +85,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, int m, int n,
   for (int e = 0; e < 8; ++e) o.e[e] = (f16)(v[e] * p.out_scale);
   *(uint4*)(p.out + (size_t)m * p.ldc + oc) = o.u;
   if (p.dup) *(uint4*)(p.out + (size_t)m * p.ldc + oc + p.dup) = o.u;
+  return o.u;
 }
 
 // Every load the block has in flight — the next tile's first DMA pieces (issued a k-step and a staging phase ago) and
@@ -748,6 +750,87 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
   }
 }
 
+// split-K second pass + the statistics pass of the GroupNorm that reads the result next (rcdm_*_gnstat): the grid, the
+// thread -> (row, 16-byte chunk) mapping and the order of every addition are gn_stats_kernel's (norm.hip), so the partials —
+// and with them the norm's output — are bit-identical to reduce + rcdm_groupnorm_silu.  Per element: the fixed-order sum of
+// the fp32 slabs and the epilogue (what splitk_reduce_kernel does), the row stored as f16, and the statistics taken from the
+// STORED halfs (what gn_stats_kernel would read back).  One launch and one read of the tensor less per norm.
+// grid (gn_splits, gn_samples); block gn_CH * gn_RPB threads; no GEGLU, no phase rows (checked by the launcher).
+__global__ __launch_bounds__(512) void splitk_reduce_gn_kernel(const IgemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* part = (float*)smem;
+  const int t = threadIdx.x;
+  const int ch = t % p.gn_CH, rl = t / p.gn_CH;
+  const int s = blockIdx.y, sp = blockIdx.x;
+  const int r_begin = sp * p.gn_rps;
+  const int r_end = min(p.gn_P, r_begin + p.gn_rps);
+  float sum[8], sq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
+  const int n = ch * 8;
+  // GN_U rows per thread and pass, as in gn_stats_kernel (the split is sized so that this is normally the block's only pass):
+  // per slab, the loads of all GN_U rows are requested before the first addition — `splits` round trips per pass
+  for (int r = r_begin + rl; r < r_end; r += GN_U * p.gn_RPB) {
+    float v[GN_U][8];
+#pragma unroll
+    for (int u = 0; u < GN_U; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+    // (both slabs of a split-2 launch requested together — 210 VGPRs — measured +0.06 ms per step against this form)
+    for (int k = 0; k < p.splits; ++k) {
+      f32x4 a[GN_U], b[GN_U];
+#pragma unroll
+      for (int u = 0; u < GN_U; ++u) {
+        const int ru = min(r + u * p.gn_RPB, r_end - 1);
+        const float* src = p.partial + ((size_t)k * p.M + (size_t)s * p.gn_P + ru) * p.N + n;
+        a[u] = *(const f32x4*)src;
+        b[u] = *(const f32x4*)(src + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < GN_U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[u][e] += a[u][e];
+          v[u][4 + e] += b[u][e];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < GN_U; ++u) {
+      const int ru = r + u * p.gn_RPB;
+      if (ru < r_end) {
+        float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // (GEGLU gates: never with statistics)
+        Pack16 o;
+        o.u = epilogue_store(p, s * p.gn_P + ru, n, v[u], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)o.e[e];
+          sum[e] += f;
+          sq[e] += f * f;
+        }
+      }
+    }
+  }
+  GnArgs ga{};
+  ga.partial = p.gn_partial; ga.G = p.gn_G; ga.cg = p.gn_cg; ga.CH = p.gn_CH; ga.RPB = p.gn_RPB; ga.splits = p.gn_splits;
+  gn_block_partials(ga, part, t, sum, sq, s, sp, r_end - r_begin);
+}
+
+// the reduce launch of a split-K GEMM / conv (every kernel family writes the same [split][M][N] fp32 slabs)
+int launch_splitk_reduce(const IgemmArgs& a, hipStream_t stream) {
+  if (a.gn_partial) {
+    const int threads = a.gn_CH * a.gn_RPB;
+    const size_t lds = (size_t)(threads + a.gn_CH) * 16 * sizeof(float);
+    hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3(a.gn_splits, a.gn_samples), dim3(threads), lds, stream, a);
+    return rcdm_check_launch();
+  }
+  const bool geglu = (a.epi & RCDM_EPI_GEGLU) != 0;
+  const size_t total = (size_t)a.M * ((geglu ? a.N / 2 : a.N) / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  return rcdm_check_launch();
+}
+
 // variant: 1 = 128x128 (2 blocks/CU), 2 = 256x256 (1), 3 = 64x64 two-slot ring (4), 4 = 64x64 four-slot ring (2),
 // 5 = 128x64 (3); 6 / 7 / 8 = the ping-pong kernel of igemm8.hip at 160x320 / 160x256 / 256x256; 9 = the 160x160 kernel of
 // igemm16.hip (2); 10 = 128x64 with a three-slot ring (2; GEMMs)   (-1 = heuristic)
@@ -1114,12 +1197,7 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
     int rc = rcdm_igemm16_launch(a, TAPS, stream);
     if (rc) return rc;
     if (a.splits > 1) {
-      const bool geglu = (a.epi & RCDM_EPI_GEGLU) != 0;
-      const size_t total = (size_t)a.M * ((geglu ? a.N / 2 : a.N) / 8);
-      int blocks = (int)((total + 255) / 256);
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
-      rc = rcdm_check_launch();
+      rc = launch_splitk_reduce(a, stream);
     }
     return rc;
   }
@@ -1133,12 +1211,7 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
     int rc = rcdm_igemm_pp_launch(a, TAPS, variant - kFirstPP, stream);
     if (rc) return rc;
     if (a.splits > 1) {
-      const bool geglu = (a.epi & RCDM_EPI_GEGLU) != 0;
-      const size_t total = (size_t)a.M * ((geglu ? a.N / 2 : a.N) / 8);
-      int blocks = (int)((total + 255) / 256);
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
-      rc = rcdm_check_launch();
+      rc = launch_splitk_reduce(a, stream);
     }
     return rc;
   }
@@ -1190,14 +1263,31 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   int rc = rcdm_check_launch();
   if (rc) return rc;
   if (a.splits > 1) {
-    const bool geglu = (a.epi & RCDM_EPI_GEGLU) != 0;
-    const size_t total = (size_t)a.M * ((geglu ? a.N / 2 : a.N) / 8);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
-    rc = rcdm_check_launch();
+    rc = launch_splitk_reduce(a, stream);
   }
   return rc;
+}
+
+// statistics geometry of the norm behind a split-K launch (rcdm_*_gnstat): 0 when the pair qualifies — `a` planned (splits
+// known), the norm reads exactly the rows this launch writes (same row count, width, row stride), takes the three-launch
+// form, and the epilogue has no GEGLU / second row copy / phase rows.  With gn_ws: also points a.gn_partial into it.
+int attach_gnstat(IgemmArgs& a, const rcdm_groupnorm_desc* gn, void* gn_ws, size_t gn_ws_bytes, bool need_ws) {
+  if (!gn) return RCDM_EINVAL;
+  if (a.splits <= 1 || (a.epi & RCDM_EPI_GEGLU) || a.dup || a.ph_rows) return RCDM_ESHAPE;
+  GnArgs g{};
+  int rc = rcdm_gn_plan(gn, g);
+  if (rc) return rc;
+  if (!rcdm_gn_three_launch(g)) return RCDM_ESHAPE;
+  if ((long long)g.samples * g.P != a.M || g.C != a.N || gn->ldx != a.ldc) return RCDM_ESHAPE;
+  if (g.CH * g.RPB > 512 || (size_t)(g.CH * g.RPB + g.CH) * 16 * sizeof(float) > 64 * 1024) return RCDM_ESHAPE;   // (the kernel's launch bound; C <= 4096)
+  const size_t need = ((size_t)g.samples * g.splits * g.G * 3 + (size_t)g.samples * g.G * 2) * sizeof(float);
+  if (need_ws) {
+    if (!gn_ws || gn_ws_bytes < need) return RCDM_EWORKSPACE;
+    a.gn_partial = (float*)gn_ws;
+  }
+  a.gn_samples = g.samples; a.gn_P = g.P; a.gn_G = g.G; a.gn_cg = g.cg; a.gn_CH = g.CH; a.gn_RPB = g.RPB;
+  a.gn_splits = g.splits; a.gn_rps = g.rows_per_split;
+  return RCDM_OK;
 }
 
 void from_gemm(const rcdm_gemm_desc* d, IgemmArgs& a) {
@@ -1340,6 +1430,31 @@ int rcdm_gemm(const rcdm_gemm_desc* d, const void* A, const void* W, const float
   return launch<1>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int rcdm_gemm_gnstat_ok(const rcdm_gemm_desc* d, const rcdm_groupnorm_desc* gn) {
+  if (!d || !gn || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  IgemmArgs a{};
+  from_gemm(d, a);
+  fill_common(a, d->split_k);
+  return attach_gnstat(a, gn, nullptr, 0, false) == RCDM_OK;
+}
+
+int rcdm_gemm_gnstat(const rcdm_gemm_desc* d, const rcdm_groupnorm_desc* gn, const void* A, const void* W, const float* bias,
+                     const float* rowvec, const void* residual, void* out, void* workspace, size_t workspace_bytes,
+                     void* gn_workspace, size_t gn_workspace_bytes, void* stream) {
+  if (!d) return RCDM_EINVAL;
+  IgemmArgs a{};
+  from_gemm(d, a);
+  a.A = (const f16*)A; a.W = (const f16*)W; a.bias = bias; a.rowvec = rowvec;
+  a.res = (const f16*)residual; a.out = (f16*)out;
+  int rc = check_common(a);
+  if (rc) return rc;
+  int variant = 0;
+  fill_common(a, d->split_k, &variant);
+  rc = attach_gnstat(a, gn, gn_workspace, gn_workspace_bytes, true);
+  if (rc) return rc;
+  return launch<1>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int rcdm_gemm_stat_parts(const rcdm_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
   IgemmArgs a{};
@@ -1448,6 +1563,34 @@ int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, cons
   if (a.epi & RCDM_EPI_GEGLU) return RCDM_ESHAPE;
   int variant = 0;
   fill_common(a, d->split_k, &variant);
+  return launch<9>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int rcdm_conv3x3_gnstat_ok(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn) {
+  if (!d || !gn || d->upsample == 2) return 0;
+  IgemmArgs a{};
+  if (from_conv(d, a) || a.Cin <= 0 || a.N <= 0) return 0;
+  fill_common(a, d->split_k);
+  return attach_gnstat(a, gn, nullptr, 0, false) == RCDM_OK;
+}
+
+int rcdm_conv3x3_gnstat(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn, const void* in, const void* W,
+                        const float* bias, const float* rowvec, const void* residual, void* out, void* workspace,
+                        size_t workspace_bytes, void* gn_workspace, size_t gn_workspace_bytes, void* stream) {
+  if (!d) return RCDM_EINVAL;
+  if (d->upsample == 2) return RCDM_ESHAPE;
+  IgemmArgs a{};
+  int rc = from_conv(d, a);
+  if (rc) return rc;
+  a.A = (const f16*)in; a.W = (const f16*)W; a.bias = bias; a.rowvec = rowvec;
+  a.res = (const f16*)residual; a.out = (f16*)out;
+  rc = check_common(a);
+  if (rc) return rc;
+  if (a.epi & RCDM_EPI_GEGLU) return RCDM_ESHAPE;
+  int variant = 0;
+  fill_common(a, d->split_k, &variant);
+  rc = attach_gnstat(a, gn, gn_workspace, gn_workspace_bytes, true);
+  if (rc) return rc;
   return launch<9>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

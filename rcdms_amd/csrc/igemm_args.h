@@ -51,6 +51,10 @@ struct IgemmArgs {
   // source pixel (phase = 2a + b; a tile lies inside one phase: ph_rows % BM == 0); W = [phase][N][4 taps][Cin]; the
   // epilogue stores virtual row m to output row img * 4HW + (2y + a) * 2W + 2x + b.  0 = not a phase launch.
   int ph_rows;
+  // split-K launches whose reduce pass also leaves the GroupNorm partial statistics of the rows it writes (rcdm_gemm_gnstat /
+  // rcdm_conv3x3_gnstat; splitk_reduce_gn_kernel): the statistics geometry of gn_plan.h for the norm that reads `out` next
+  float* gn_partial;            // null: plain reduce
+  int gn_samples, gn_P, gn_G, gn_cg, gn_CH, gn_RPB, gn_splits, gn_rps;
 };
 // output row of virtual row m of a phase launch (IgemmArgs::ph_rows): the (2y + a, 2x + b) pixel of the upsampled image
 __device__ __forceinline__ int phase_out_row(const IgemmArgs& p, int m) {

@@ -7,23 +7,11 @@
 // motion_module.py:236,243; PositionalEncoding.forward motion_module.py:265-267.
 #include <stdlib.h>
 #include "common.h"
+#include "gn_plan.h"
 
 namespace {
 
-constexpr int GN_U = 8;  // 16-byte loads a thread of the stats / apply kernels keeps in flight
 int g_gn_fold_mode = -1;
-
-struct GnArgs {
-  const f16* x;
-  f16* y;
-  const float* gamma;
-  const float* beta;
-  float* partial;  // [samples][groups][splits][3] = (count, mean, M2)
-  float* stat;     // [samples][groups][2] = (mean, rstd)
-  int samples, P, C, G, cg, CH, RPB, ldx, ldy, splits, rows_per_split;
-  float eps;
-  int silu;
-};
 
 // grid (splits, samples); block CH*RPB threads; thread (rl, ch) owns 16-B chunk ch of rows rl+k*RPB.
 __global__ void gn_stats_kernel(const GnArgs p) {
@@ -57,41 +45,7 @@ __global__ void gn_stats_kernel(const GnArgs p) {
         sq[e] += f * f;
       }
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    part[t * 16 + e] = sum[e];
-    part[t * 16 + 8 + e] = sq[e];
-  }
-  __syncthreads();
-  // column sums first (CH * 16 values, each over the RPB row-threads, spread over the whole block), then the G groups:
-  // the one-step form (G threads walking RPB * cg entries each) was a 120-read serial tail on 32 threads per block
-  const float* colsum = part;  // one row-thread per chunk: the per-thread sums ARE the column sums
-  if (p.RPB > 1) {
-    float* cs = part + blockDim.x * 16;
-    for (int o = t; o < p.CH * 16; o += blockDim.x) {
-      const int c = o >> 4, k = o & 15;
-      float a = 0.f;
-      for (int r = 0; r < p.RPB; ++r) a += part[(r * p.CH + c) * 16 + k];
-      cs[o] = a;
-    }
-    colsum = cs;
-    __syncthreads();
-  }
-  if (t < p.G) {
-    float gs = 0.f, gq = 0.f;
-    for (int c = t * p.cg; c < (t + 1) * p.cg; ++c) {
-      gs += colsum[(c >> 3) * 16 + (c & 7)];
-      gq += colsum[(c >> 3) * 16 + 8 + (c & 7)];
-    }
-    const float n = (float)(r_end - r_begin) * (float)p.cg;
-    const float mean = n > 0.f ? gs / n : 0.f;
-    float m2 = gq - gs * mean;
-    if (m2 < 0.f) m2 = 0.f;
-    float* o = p.partial + (((size_t)s * p.G + t) * p.splits + sp) * 3;
-    o[0] = n;
-    o[1] = mean;
-    o[2] = m2;
-  }
+  gn_block_partials(p, part, t, sum, sq, s, sp, r_end - r_begin);
 }
 
 // one wave per (sample, group): lanes take splits lane, lane+64, ... in order, then a fixed xor-butterfly
@@ -376,7 +330,7 @@ int gn_fused_bundle(int G, int cg) {
   return 0;
 }
 
-int gn_plan(const rcdm_groupnorm_desc* d, GnArgs& a) {
+int gn_plan(const rcdm_groupnorm_desc* d, GnArgs& a) {   // (rcdm_gn_plan for igemm.hip: below)
   if (d->samples <= 0 || d->rows_per_sample <= 0 || d->C <= 0 || d->groups <= 0) return RCDM_EINVAL;
   if ((d->C & 7) || (d->C % d->groups) || (d->ldx & 7) || (d->ldy & 7)) return RCDM_ESHAPE;
   if (d->groups > 64 || d->C > 8192) return RCDM_ESHAPE;
@@ -644,7 +598,50 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict
   }
 }
 
+bool gn_single_launch(const GnArgs& a) {
+  static int fused_mode = -1;  // RCDM_GN_FUSED=0: three-launch form everywhere (A/B switch)
+  if (fused_mode < 0) {
+    const char* e = getenv("RCDM_GN_FUSED");
+    fused_mode = e ? atoi(e) : 1;
+  }
+  const int gb = gn_fused_bundle(a.G, a.cg);
+  // one block per (sample, bundle) pays up to a few hundred rows per sample (measured: 15 -> 9 us at 320 rows, but
+  // 17 -> 22 us at 1280 and 25 -> 64 us at 4096: a single block streams its slab too slowly)
+  return fused_mode && gb && a.samples * (a.G / gb) >= 48 && a.P <= 512;
+}
+
+// finalize + apply of the three-launch form (partials already in a.partial)
+int gn_finalize_apply(GnArgs& a, hipStream_t stream) {
+  const int threads = a.CH * a.RPB;
+  // OFF by default: measured +0.05 ms per step (18.08 -> 18.13 ms, three interleaved pairs on one box) — the ~430 apply blocks
+  // of a 32x32-level per-frame norm each pay a partials round trip + eight butterflies, more than the 4.9 us launch they replace.
+  // RCDM_GN_FOLD=1 / rcdm_set_groupnorm_fold(1) turns it on (bit-identical results).
+  int& fold_mode = g_gn_fold_mode;
+  if (fold_mode < 0) {
+    const char* e = getenv("RCDM_GN_FOLD");
+    fold_mode = e ? atoi(e) : 0;
+  }
+  const int threads64 = (threads + 63) / 64 * 64;
+  const bool fold = fold_mode && a.samples >= 4 && a.splits <= 128 && a.G <= 64 && threads64 <= 1024;
+  if (!fold) {
+    const int nsg = a.samples * a.G;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, stream, a);
+    const int rc = rcdm_check_launch();
+    if (rc) return rc;
+  }
+  int bps = (a.P + a.RPB * 8 - 1) / (a.RPB * 8);  // ~8 rows per thread
+  const int cap = (2048 + a.samples - 1) / a.samples;
+  if (bps > cap) bps = cap;
+  if (bps < 1) bps = 1;
+  if (fold) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(bps, a.samples), dim3(threads64), 0, stream, a);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(bps, a.samples), dim3(threads), 0, stream, a);
+  return rcdm_check_launch();
+}
+
 }  // namespace
+
+int rcdm_gn_plan(const rcdm_groupnorm_desc* d, GnArgs& a) { return gn_plan(d, a); }
+bool rcdm_gn_three_launch(const GnArgs& a) { return !gn_single_launch(a) && a.CH * a.RPB <= 1024; }
 
 extern "C" {
 
@@ -669,15 +666,8 @@ int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float
   if (!workspace || workspace_bytes < need) return RCDM_EWORKSPACE;
   hipStream_t stream0 = (hipStream_t)stream_;
   {
-    static int fused_mode = -1;  // RCDM_GN_FUSED=0: three-launch form everywhere (A/B switch)
-    if (fused_mode < 0) {
-      const char* e = getenv("RCDM_GN_FUSED");
-      fused_mode = e ? atoi(e) : 1;
-    }
-    const int gb = gn_fused_bundle(a.G, a.cg);
-    // one block per (sample, bundle) pays up to a few hundred rows per sample (measured: 15 -> 9 us at 320 rows, but
-    // 17 -> 22 us at 1280 and 25 -> 64 us at 4096: a single block streams its slab too slowly)
-    if (fused_mode && gb && a.samples * (a.G / gb) >= 48 && a.P <= 512) {
+    if (gn_single_launch(a)) {
+      const int gb = gn_fused_bundle(a.G, a.cg);
       GnFusedArgs f;
       f.x = (const f16*)x; f.y = (f16*)y; f.gamma = gamma; f.beta = beta;
       f.P = a.P; f.cg = a.cg; f.GB = gb; f.NCHK = gb * a.cg / 8; f.RPB = 256 / f.NCHK;
@@ -702,29 +692,28 @@ int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.splits, a.samples), dim3(threads), stats_lds, stream, a);
   rc = rcdm_check_launch();
   if (rc) return rc;
-  // OFF by default: measured +0.05 ms per step (18.08 -> 18.13 ms, three interleaved pairs on one box) — the ~430 apply blocks
-  // of a 32x32-level per-frame norm each pay a partials round trip + eight butterflies, more than the 4.9 us launch they replace.
-  // RCDM_GN_FOLD=1 / rcdm_set_groupnorm_fold(1) turns it on (bit-identical results).
-  int& fold_mode = g_gn_fold_mode;
-  if (fold_mode < 0) {
-    const char* e = getenv("RCDM_GN_FOLD");
-    fold_mode = e ? atoi(e) : 0;
-  }
-  const int threads64 = (threads + 63) / 64 * 64;
-  const bool fold = fold_mode && a.samples >= 4 && a.splits <= 128 && a.G <= 64 && threads64 <= 1024;
-  if (!fold) {
-    const int nsg = a.samples * a.G;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, stream, a);
-    rc = rcdm_check_launch();
-    if (rc) return rc;
-  }
-  int bps = (a.P + a.RPB * 8 - 1) / (a.RPB * 8);  // ~8 rows per thread
-  const int cap = (2048 + a.samples - 1) / a.samples;
-  if (bps > cap) bps = cap;
-  if (bps < 1) bps = 1;
-  if (fold) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(bps, a.samples), dim3(threads64), 0, stream, a);
-  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(bps, a.samples), dim3(threads), 0, stream, a);
-  return rcdm_check_launch();
+  return gn_finalize_apply(a, stream);
+}
+
+int rcdm_groupnorm_prestat_ok(const rcdm_groupnorm_desc* d) {
+  GnArgs a{};
+  if (!d || gn_plan(d, a)) return 0;
+  return rcdm_gn_three_launch(a) ? 1 : 0;
+}
+
+int rcdm_groupnorm_silu_prestat(const rcdm_groupnorm_desc* d, const void* x, const float* gamma, const float* beta, void* y,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!d || !x || !gamma || !beta || !y) return RCDM_EINVAL;
+  GnArgs a{};
+  int rc = gn_plan(d, a);
+  if (rc) return rc;
+  if (!rcdm_gn_three_launch(a)) return RCDM_ESHAPE;   // this descriptor's norm is a single launch: nobody can have left partials
+  const size_t need = ((size_t)a.samples * a.splits * a.G * 3 + (size_t)a.samples * a.G * 2) * sizeof(float);
+  if (!workspace || workspace_bytes < need) return RCDM_EWORKSPACE;
+  a.x = (const f16*)x; a.y = (f16*)y; a.gamma = gamma; a.beta = beta;
+  a.partial = (float*)workspace;
+  a.stat = a.partial + (size_t)a.samples * a.splits * a.G * 3;
+  return gn_finalize_apply(a, (hipStream_t)stream_);
 }
 
 int rcdm_groupnorm_stats(const rcdm_groupnorm_desc* d, const void* x, float* stat, void* workspace, size_t workspace_bytes,

@@ -120,8 +120,24 @@ if _DROP:
 # ------------------------------------------------------------------------------------------------
 # single-kernel emitters
 
+def _gn_handoff(plan, out, N, gn, ok_fn, d):
+    """gn = (samples, rows_per_sample, groups) of the GroupNorm that reads `out` NEXT (or None).  Where the launch is split-K
+    and the library takes the pair (rcdm_*_gnstat_ok), its reduce pass also leaves that norm's partial statistics in the
+    shared "gn_ws" scratch: returns (GroupNormDesc, workspace Buf) and the caller records plan.gn_ready after adding its
+    op; emit_groupnorm, if it is the very next op and reads exactly these rows, then launches finalize + apply only."""
+    if gn is None or not GN_PRESTAT:
+        return None
+    samples, rps, groups = gn
+    if samples * rps != out.M or N % groups:
+        return None
+    gnd = hip.GroupNormDesc(samples, rps, N, groups, out.ld, out.ld, 1e-5, 0)
+    if not ok_fn(d, gnd):
+        return None
+    return gnd, plan.scratch("gn_ws", hip.groupnorm_workspace_bytes(gnd))
+
+
 def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geglu=False, scale=1.0, split_k=0,
-              gelu=False, dup_rows=0, stat=False, lnx=None):
+              gelu=False, dup_rows=0, stat=False, lnx=None, gn=None):
     """out[M][N or N/2] = epi(A[M][K] W[N][K]^T); rowvec = (tensor, elem_offset, ldt, rows_per_sample).
     Deferred LayerNorm (rcdm_gemm_lnx): stat=True — also write the row statistics of the stored rows and RETURN their handle
     (None when this shape has no statistics-producing launch: the caller then emits the stand-alone LayerNorm);
@@ -168,8 +184,14 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
         x = hip.Lnx(0, handle.parts if handle else 0, handle.rows if handle else 0, 0, lnx[0].parts if lnx else 0,
                     lnx[0].rows if lnx else 0, lnx[1].data_ptr() if lnx else 0, 1e-5, K)
 
+    hand = _gn_handoff(plan, out, N, gn, hip.gemm_gnstat_ok, d) if (x is None and not geglu and not gelu) else None
+
     def op():
         rvp = (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0
+        if hand is not None:
+            hip.gemm_gnstat(d, hand[0], A.ptr, Wt.data_ptr(), bptr, rvp, residual.ptr if residual is not None else 0, out.ptr,
+                            ws.ptr, ws.nbytes, hand[1].ptr, hand[1].nbytes)
+            return
         if x is not None:
             x.stat_out = handle.buf.ptr if handle is not None else 0
             x.stat_in = lnx[0].buf.ptr if lnx is not None else 0
@@ -178,13 +200,16 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
             return
         hip.gemm(d, A.ptr, Wt.data_ptr(), bptr, rvp, residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
     n_before = len(plan.ops)
-    plan.add(op, f"gemm M={A.M} N={N} K={K} epi={epi}" + (" lnx" if lnx is not None else "") + (" stat" if handle is not None else ""))
+    plan.add(op, f"gemm M={A.M} N={N} K={K} epi={epi}" + (" lnx" if lnx is not None else "") + (" stat" if handle is not None else "")
+             + (" gnstat" if hand is not None else ""))
     plan.keep += [Wt, bias, rv_t, x, lnx[1] if lnx else None]
     if len(plan.ops) > n_before:
         plan.op_weights[len(plan.ops) - 1] = Wt
     plan.n_launch += 2 if wsb else 1
     if len(plan.ops) == n_before:   # the op was left out (RCDM_DROP_OPS)
         return None
+    if hand is not None:
+        plan.gn_ready = dict(n_ops=len(plan.ops), key=out.ptr_key(), M=out.M, C=N, gn=gn)
     return handle
 
 
@@ -196,7 +221,7 @@ def gemm_lnx_ok(M, N, K, lda, ldc, geglu=False, dup_rows=0):
 
 
 def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=None, rowvec=None, residual=None,
-                 scale=1.0, split_k=0, pad_after_only=0, dup_rows=0):
+                 scale=1.0, split_k=0, pad_after_only=0, dup_rows=0, gn=None):
     epi = 0
     if bias is not None:
         epi |= hip.EPI_BIAS
@@ -211,13 +236,21 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
     bptr = bias.data_ptr() if bias is not None else 0
     rv_t, rv_off = (rowvec[0], rowvec[1]) if rowvec else (None, 0)
 
+    hand = _gn_handoff(plan, out, cout, gn, hip.conv3x3_gnstat_ok, d) if up != 2 else None
+
     def op():
-        hip.conv3x3(d, x.ptr, Wt.data_ptr(), bptr, (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0,
-                    residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
+        rvp = (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0
+        if hand is not None:
+            hip.conv3x3_gnstat(d, hand[0], x.ptr, Wt.data_ptr(), bptr, rvp, residual.ptr if residual is not None else 0, out.ptr,
+                               ws.ptr, ws.nbytes, hand[1].ptr, hand[1].nbytes)
+            return
+        hip.conv3x3(d, x.ptr, Wt.data_ptr(), bptr, rvp, residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
     n_before = len(plan.ops)
-    plan.add(op, f"conv3x3 {n_img}x{H}x{W} {cin}->{cout} s={stride} up={up} epi={epi}")
+    plan.add(op, f"conv3x3 {n_img}x{H}x{W} {cin}->{cout} s={stride} up={up} epi={epi}" + (" gnstat" if hand is not None else ""))
     if len(plan.ops) > n_before:
         plan.op_weights[len(plan.ops) - 1] = Wt
+        if hand is not None:
+            plan.gn_ready = dict(n_ops=len(plan.ops), key=out.ptr_key(), M=out.M, C=cout, gn=gn)
     plan.keep += [Wt, bias, rv_t]
     plan.n_launch += 2 if wsb else 1
 
@@ -236,15 +269,28 @@ def emit_upsample_conv(plan, pk, wkey, x, n_img, H, W, c, out, bias):
         emit_conv3x3(plan, x, n_img, H, W, pk.conv3x3(wkey), c, c, out, up=1, bias=bias)
 
 
+# A split-K producer whose reduce pass leaves the statistics of the GroupNorm behind it (rcdm_*_gnstat; _gn_handoff): the
+# norm then runs finalize + apply only.  RCDM_GN_PRESTAT=0: every norm takes its own statistics pass (same-process A/B).
+GN_PRESTAT = os.environ.get("RCDM_GN_PRESTAT", "1") != "0"
+
+
 def emit_groupnorm(plan, x, samples, rows_per_sample, gamma, beta, eps, silu, out, groups=32):
     d = hip.GroupNormDesc(samples, rows_per_sample, x.C, groups, x.ld, out.ld, eps, int(silu))
     ws = plan.scratch("gn_ws", hip.groupnorm_workspace_bytes(d))
+    rdy = getattr(plan, "gn_ready", None)
+    plan.gn_ready = None
+    pre = (rdy is not None and rdy["n_ops"] == len(plan.ops) and rdy["key"] == x.ptr_key() and rdy["M"] == x.M and
+           rdy["C"] == x.C and rdy["gn"] == (samples, rows_per_sample, groups) and hip.groupnorm_prestat_ok(d))
+    assert rdy is None or rdy["n_ops"] != len(plan.ops) or pre, "a producer left GroupNorm statistics that nobody consumes"
 
     def op():
-        hip.groupnorm_silu(d, x.ptr, gamma.data_ptr(), beta.data_ptr(), out.ptr, ws.ptr, ws.nbytes)
-    plan.add(op, f"groupnorm S={samples} R={rows_per_sample} C={x.C} silu={int(silu)}")
+        if pre:   # the partial statistics are in ws already (the producer's reduce pass)
+            hip.groupnorm_silu_prestat(d, x.ptr, gamma.data_ptr(), beta.data_ptr(), out.ptr, ws.ptr, ws.nbytes)
+        else:
+            hip.groupnorm_silu(d, x.ptr, gamma.data_ptr(), beta.data_ptr(), out.ptr, ws.ptr, ws.nbytes)
+    plan.add(op, f"groupnorm S={samples} R={rows_per_sample} C={x.C} silu={int(silu)}" + (" prestat" if pre else ""))
     plan.keep += [gamma, beta]
-    plan.n_launch += 3
+    plan.n_launch += 2 if pre else 3
 
 
 def emit_groupnorm_stats(plan, x, samples, rows_per_sample, gamma, beta, eps, groups=32):
@@ -675,23 +721,25 @@ class Geo:
         self.M = self.n_img * self.hw
 
 
-def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, dup_rows=0):
+def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, dup_rows=0, out_gn=None):
     """ResnetBlock3D.forward (src/models/resnet.py:182-212).  temb = (tensor [b][ldt] fp32, col offset, ldt)
-    = this block's slice of the batched time_emb_proj(silu(emb)) table.  x may be a concat view."""
+    = this block's slice of the batched time_emb_proj(silu(emb)) table.  x may be a concat view.
+    out_gn = (samples, rows_per_sample, groups) of the GroupNorm that reads `out` as the very next op (the norm in front of
+    the transformer / motion module / ResNet block behind this one), or None: a split-K conv2 then leaves its statistics."""
     g = geo
+    a1 = plan.rows("norm", g.M, x.C)
+    emit_groupnorm(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, True, a1, groups)   # (first: x may carry a producer's statistics)
     res = x
     if w.shortcut is not None:
         res = plan.rows("res_sc", g.M, w.cout)
         emit_gemm(plan, x, w.shortcut, w.cout, w.cin, res, bias=w.sb)
-    a1 = plan.rows("norm", g.M, x.C)
-    emit_groupnorm(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, True, a1, groups)
     h1 = plan.rows("res_h1", g.M, w.cout)
     emit_conv3x3(plan, a1, g.n_img, g.H, g.W, w.conv1, w.cin, w.cout, h1, bias=w.cb1,
-                 rowvec=(temb[0], temb[1], temb[2], g.f * g.hw))
+                 rowvec=(temb[0], temb[1], temb[2], g.f * g.hw), gn=(g.b, g.f * g.hw, groups))
     a2 = plan.rows("norm", g.M, w.cout)
     emit_groupnorm(plan, h1, g.b, g.f * g.hw, w.g2, w.b2, eps, True, a2, groups)
     emit_conv3x3(plan, a2, g.n_img, g.H, g.W, w.conv2, w.cout, w.cout, out, bias=w.cb2, residual=res, scale=out_scale,
-                 dup_rows=dup_rows)
+                 dup_rows=dup_rows, gn=out_gn)
 
 
 # rcdm_ff_fused (rowff.hip): LayerNorm -> GEGLU feed-forward -> + residual as ONE row-stationary launch, for the channel
@@ -762,7 +810,7 @@ def emit_rowchain(plan, a_in, res, tok, a_bias, ln, pe, stream, tail, out, rows_
     plan.n_launch += 1
 
 
-def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None, tok_stat=None, lnx=None, z=None):
+def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None, tok_stat=None, lnx=None, z=None, out_gn=None):
     """x += FeedForward_geglu(LayerNorm(x))  (attention.py:514 / motion_module.py:243), in place on tok.
     stream: (fragment-major weight stream, packed b1) of Packer.ff_stream, or None for the unfused chain.
     tok_stat / lnx: row statistics of tok from the GEMM that wrote it + Packer.lnx_geglu operands — the LayerNorm then
@@ -778,7 +826,7 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None,
         else:
             emit_layernorm(plan, tok, ln_g, ln_b, a)
             emit_gemm(plan, a, ff1, 8 * C, C, gg, bias=ff1_b, geglu=True)
-        emit_gemm(plan, cat, ffz.W, C, 5 * C, out, bias=ffz.b, residual=x)
+        emit_gemm(plan, cat, ffz.W, C, 5 * C, out, bias=ffz.b, residual=x, gn=out_gn)   # (out_gn: the norm that reads `out` next)
         return
     if stream is not None and M >= CHAIN_MIN_ROWS:
         ws, b1p = stream
@@ -800,7 +848,7 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None,
 
 
 def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False, ctx_img=None, pre=None, post=None,
-                     tok_stat=None, z=None):
+                     tok_stat=None, z=None, out_gn=None):
     """BasicTransformerBlock.forward (src/models/attention.py:479-526) in place on tok [n_seq*Lq][C]:
     h += attn1(LN1(h)); h += attn2(LN2(h), ctx); h += FF(LN3(h)).  ctx_kv: Rows [n_seq*L][2C] = [K | V] of the context.
     shared_half: the two halves of tok (the CFG halves of a denoising step) hold IDENTICAL rows on entry — everything up
@@ -863,7 +911,7 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
         st = emit_gemm(plan, ao, w.o2, C, C, tok, bias=w.o2_b, residual=tok, stat=want_ff)
     if w.geglu:
         emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, M, C, stream=w.ff_stream,
-                tok_stat=st if st is not None and st.M >= M else None, lnx=w.lnx_ff, z=z)
+                tok_stat=st if st is not None and st.M >= M else None, lnx=w.lnx_ff, z=z, out_gn=out_gn)
     else:   # FeedForward("gelu"): Linear -> exact GELU -> Linear (stage-1 prior blocks)
         emit_layernorm(plan, tok, w.ln[2][0], w.ln[2][1], a)
         hid = plan.rows("geglu", M, 4 * C)
@@ -881,7 +929,7 @@ def ffz_rows(plan, w, M, C, x, out):
     return None, plan.rows("tok", M, C)
 
 
-def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_half=False, ctx_img=None):
+def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_half=False, ctx_img=None, out_gn=None):
     """Transformer3DModel.forward + BasicTransformerBlock.forward (src/models/attention.py:318-365,479-526).
     ctx_kv: Rows [n_img*L][2C] = [K | V] projections of the context for this site (computed per context).
     shared_half: see emit_basic_block (x holds identical halves; both halves of `out` are still written in full)."""
@@ -903,9 +951,9 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     post = (w.ch_o2_ffz, x, w.proj_out_b, out) if (getattr(w, "ch_o2_ffz", None) is not None and w.has_cross and
                                                    g.M >= CHAIN_MIN_ROWS) else None
     emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img, pre=pre,
-                     post=post, tok_stat=tok_stat, z=z)
+                     post=post, tok_stat=tok_stat, z=z, out_gn=out_gn)
     if post is None and z is None:
-        emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
+        emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x, gn=out_gn)
 
 
 def emit_ctx_kv(plan, w, ctx16, ctx_kv, n_seq=0, L=0, heads=0):
@@ -917,7 +965,7 @@ def emit_ctx_kv(plan, w, ctx16, ctx_kv, n_seq=0, L=0, heads=0):
     return None
 
 
-def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
+def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False, out_gn=None):
     """VanillaTemporalModule -> TemporalTransformer3DModel.forward -> TemporalTransformerBlock.forward
     (src/models/motion_module.py:87-93,147-182,234-246).  prior_state (stage-1 prior, :150-153,172-174): the rows are
     (b f) x n tokens (geo.hw = n), the leading norm is the LayerNorm `prior_norm` instead of the per-frame GroupNorm."""
@@ -968,9 +1016,9 @@ def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False):
         emit_temporal_attn(plan, qkv, g.b, g.f, g.hw, heads, d_head, ao)
         st = emit_gemm(plan, ao, at.o, C, C, tok, bias=at.o_b, residual=tok, stat=want_stat)
     emit_ff(plan, tok, w.ff_ln[0], w.ff_ln[1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, g.M, C, stream=w.ff_stream, tok_stat=st,
-            lnx=w.lnx_ff, z=z)
+            lnx=w.lnx_ff, z=z, out_gn=out_gn)
     if z is None:
-        emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x)
+        emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x, gn=out_gn)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1106,37 +1154,47 @@ class UNetProgram:
         self._ctx_plan = ctx_plan
         site = [0]
 
-        def transformer(p, x, geo, out, shared_half=False):
+        def transformer(p, x, geo, out, shared_half=False, out_gn=None):
             small = geo.M < CHAIN_MIN_ROWS   # below the chain kernels' row count: deferred LayerNorms + composed proj_out
             w = pack_transformer(pk, p, lnx=small or shared_half, ffz=small)
             kv = plan.rows(f"ctx_kv{site[0]}", geo.n_img * L, 2 * w.C, unique=True)
             site[0] += 1
             img = emit_ctx_kv(ctx_plan, w, self.ctx16, kv, geo.n_img, L, heads)
-            emit_transformer(plan, w, x, geo, kv, L, heads, out, groups, shared_half=shared_half, ctx_img=img)
+            emit_transformer(plan, w, x, geo, kv, L, heads, out, groups, shared_half=shared_half, ctx_img=img, out_gn=out_gn)
 
-        def motion(p, x, geo, out):
-            emit_motion(plan, pack_motion(pk, p, n_attn, lnx=geo.M < CHAIN_MIN_ROWS), x, geo, mheads, out, groups)
+        def motion(p, x, geo, out, out_gn=None):
+            emit_motion(plan, pack_motion(pk, p, n_attn, lnx=geo.M < CHAIN_MIN_ROWS), x, geo, mheads, out, groups, out_gn=out_gn)
 
-        def layer(pb, j, kind_attn, res, x, geo, final_out, shared=False):
+        def layer(pb, j, kind_attn, res, x, geo, final_out, shared=False, next_resnet=False):
             """resnet -> [transformer] -> [motion]; the LAST op writes final_out, the others ping-pong.
             shared: the first layer under shared_prefix — the ResNet block runs on the first half of the batch (its
-            GroupNorm statistics are per sample, its time-embedding row per sample: nothing crosses the halves)."""
+            GroupNorm statistics are per sample, its time-embedding row per sample: nothing crosses the halves).
+            next_resnet: final_out is, as it stands, the input of another ResNet block of this geometry (down path: the next
+            layer of the block) — its norm1 is then the op emitted right after this layer's last one."""
             stages = ["r"] + (["t"] if kind_attn else []) + (["m"] if has_motion(res) else [])
             cur = x
             cout = sd[pb + f"resnets.{j}.conv1.weight"].shape[0]
             for si, st in enumerate(stages):
                 dst = final_out if si == len(stages) - 1 else plan.rows(f"blk{si % 2}", geo.M, cout)
+                # the GroupNorm that reads dst as the very next op: per frame in front of a transformer / motion module
+                # (attention.py:328, motion_module.py:162), across the frames in front of a ResNet block (resnet.py:185)
+                if si + 1 < len(stages):
+                    nxt = (geo.n_img, geo.hw, groups)
+                else:
+                    nxt = (geo.b, geo.f * geo.hw, groups) if next_resnet else None
+                if shared and si + 1 < len(stages) and stages[si + 1] == "t":
+                    nxt = None   # (the shared-prefix transformer norms half the rows)
                 if st == "r":
                     pr = pb + f"resnets.{j}."
                     if shared:
                         emit_resnet(plan, pack_resnet(pk, pr), cur.rows(0, g0h.M), g0h, temb_of(pr), dst.rows(0, g0h.M),
                                     eps, groups, dup_rows=g0h.M)
                     else:
-                        emit_resnet(plan, pack_resnet(pk, pr), cur, geo, temb_of(pr), dst, eps, groups)
+                        emit_resnet(plan, pack_resnet(pk, pr), cur, geo, temb_of(pr), dst, eps, groups, out_gn=nxt)
                 elif st == "t":
-                    transformer(pb + f"attentions.{j}.", cur, geo, dst, shared_half=shared)
+                    transformer(pb + f"attentions.{j}.", cur, geo, dst, shared_half=shared, out_gn=nxt)
                 else:
-                    motion(pb + f"motion_modules.{j}.", cur, geo, dst)
+                    motion(pb + f"motion_modules.{j}.", cur, geo, dst, out_gn=nxt)
                 cur = dst
             return cur
 
@@ -1146,7 +1204,7 @@ class UNetProgram:
             pb = f"down_blocks.{i}."
             for j in range(lpb):
                 cur = layer(pb, j, kind == "CrossAttnDownBlock3D", 2 ** i, cur, geos[i], skip_view(k),
-                            shared=shared_prefix and i == 0 and j == 0)
+                            shared=shared_prefix and i == 0 and j == 0, next_resnet=j + 1 < lpb)
                 k += 1
             if i != nlev - 1:
                 dsw = pk.conv3x3(pb + "downsamplers.0.conv.weight")
@@ -1160,7 +1218,7 @@ class UNetProgram:
         gm = geos[-1]
         m0 = plan.rows("blk0", gm.M, boc[-1])
         emit_resnet(plan, pack_resnet(pk, "mid_block.resnets.0."), cur, gm, temb_of("mid_block.resnets.0."), m0,
-                    eps, groups, 1.0 / cfg.get("mid_block_scale_factor", 1))
+                    eps, groups, 1.0 / cfg.get("mid_block_scale_factor", 1), out_gn=(gm.n_img, gm.hw, groups))
         m1 = plan.rows("blk1", gm.M, boc[-1])
         transformer("mid_block.attentions.0.", m0, gm, m1)
         cur = m1

@@ -105,6 +105,12 @@ SYMBOLS = {
     "rcdm_groupnorm_workspace_bytes": (_SZ, [C.POINTER(GroupNormDesc)]),
     "rcdm_groupnorm_silu": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _SZ, _P]),
+    "rcdm_groupnorm_prestat_ok": (C.c_int, [C.POINTER(GroupNormDesc)]),
+    "rcdm_groupnorm_silu_prestat": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _SZ, _P]),
+    "rcdm_gemm_gnstat_ok": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GroupNormDesc)]),
+    "rcdm_gemm_gnstat": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
+    "rcdm_conv3x3_gnstat_ok": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(GroupNormDesc)]),
+    "rcdm_conv3x3_gnstat": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
     "rcdm_softmax_rows": (C.c_int, [_I, _I, _I, _I, C.c_float, _P, _P, _P]),
     "rcdm_layernorm": (C.c_int, [C.POINTER(LayerNormDesc), _P, _P, _P, _P, _P, _P]),
     "rcdm_flash_attn": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
@@ -239,6 +245,33 @@ def groupnorm_workspace_bytes(desc):
 def groupnorm_silu(desc, x, gamma, beta, y, ws_ptr, ws_bytes, stream=None):
     _check(load().rcdm_groupnorm_silu(C.byref(desc), x, gamma, beta, y, ws_ptr, ws_bytes,
                                       stream_ptr() if stream is None else stream), "rcdm_groupnorm_silu")
+
+
+def groupnorm_silu_prestat(desc, x, gamma, beta, y, ws_ptr, ws_bytes, stream=None):
+    _check(load().rcdm_groupnorm_silu_prestat(C.byref(desc), x, gamma, beta, y, ws_ptr, ws_bytes,
+                                              stream_ptr() if stream is None else stream), "rcdm_groupnorm_silu_prestat")
+
+
+def groupnorm_prestat_ok(desc):
+    return bool(load().rcdm_groupnorm_prestat_ok(C.byref(desc)))
+
+
+def gemm_gnstat_ok(desc, gn):
+    return bool(load().rcdm_gemm_gnstat_ok(C.byref(desc), C.byref(gn)))
+
+
+def gemm_gnstat(desc, gn, A, W, bias, rowvec, residual, out, ws_ptr, ws_bytes, gn_ws_ptr, gn_ws_bytes, stream=None):
+    _check(load().rcdm_gemm_gnstat(C.byref(desc), C.byref(gn), A, W, bias, rowvec, residual, out, ws_ptr, ws_bytes, gn_ws_ptr,
+                                   gn_ws_bytes, stream_ptr() if stream is None else stream), "rcdm_gemm_gnstat")
+
+
+def conv3x3_gnstat_ok(desc, gn):
+    return bool(load().rcdm_conv3x3_gnstat_ok(C.byref(desc), C.byref(gn)))
+
+
+def conv3x3_gnstat(desc, gn, x, W, bias, rowvec, residual, out, ws_ptr, ws_bytes, gn_ws_ptr, gn_ws_bytes, stream=None):
+    _check(load().rcdm_conv3x3_gnstat(C.byref(desc), C.byref(gn), x, W, bias, rowvec, residual, out, ws_ptr, ws_bytes, gn_ws_ptr,
+                                      gn_ws_bytes, stream_ptr() if stream is None else stream), "rcdm_conv3x3_gnstat")
 
 
 def groupnorm_stats(desc, x, stat, ws_ptr, ws_bytes, stream=None):

@@ -497,6 +497,101 @@ def test_groupnorm(hiplib, b, f, H, W, C, cross, silu):
     close(rows_to_5d(y, b, C, f, H, W), ref)
 
 
+@pytest.mark.parametrize("kind,b,f,H,W,cin,cout,cross,split,variant", [
+    ("conv", 2, 5, 32, 32, 128, 640, True, 2, -1),     # conv1 -> norm2 of a 32x32-level ResNet block (cross-frame statistics)
+    ("conv", 2, 5, 32, 32, 128, 640, False, 3, -1),    # conv2 (+ residual) -> the per-frame norm in front of a transformer
+    ("conv", 2, 5, 16, 16, 128, 320, True, 4, 9),      # 160x160 tiles, cg = 10 (groups straddle 16-byte chunks)
+    ("conv", 1, 5, 24, 24, 64, 960, False, 2, 1),      # one sample per image, 576 rows each
+    ("gemm", 2, 5, 32, 32, 1280, 640, False, 4, -1),   # the proj_out-composed feed-forward GEMM -> a motion module's norm
+    ("gemm", 2, 5, 16, 16, 640, 640, True, 2, 5),
+])
+def test_splitk_gnstat_is_bit_identical(hiplib, kind, b, f, H, W, cin, cout, cross, split, variant):
+    """rcdm_conv3x3_gnstat / rcdm_gemm_gnstat + rcdm_groupnorm_silu_prestat (the split-K reduce pass leaves the partial
+    statistics of the GroupNorm that reads its output next: resnet.py:185-202 conv1 -> norm2, attention.py:328 /
+    motion_module.py:162 behind conv2 or the feed-forward) against the separate launches rcdm_conv3x3 / rcdm_gemm +
+    rcdm_groupnorm_silu: the producer's rows AND the norm's output must be bit-identical (statistics from the stored halfs,
+    same order of additions), and the norm matches the oracle."""
+    from rcdms_amd import hip
+    hip.set_igemm_variant(variant)
+    g = torch.Generator().manual_seed(31 + cin + cout + split)
+    n_img, M = b * f, b * f * H * W
+    bias = torch.randn(cout, generator=g).to(DEV)
+    rv = torch.randn(b, cout, generator=g).to(DEV)                       # per-sample row vector (time_emb_proj rows)
+    res = h16(torch.randn(M, cout, generator=g)).half().to(DEV)
+    gamma, beta = torch.randn(cout, generator=g).to(DEV), torch.randn(cout, generator=g).to(DEV)
+    samples, rps = (b, f * H * W) if cross else (n_img, H * W)
+    ldc = cout + 8
+    gnd = hip.GroupNormDesc(samples, rps, cout, 32, ldc, cout, 1e-5 if cross else 1e-6, int(cross))
+    epi = 1 | 2 | 4
+    if kind == "conv":
+        x = h16(torch.randn(M, cin, generator=g)).half().to(DEV)
+        w = h16(torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(DEV)
+        d = hip.ConvDesc(n_img, H, W, cin, cout, 1, 0, cin, ldc, cout, epi, f * H * W, cout, 1.0, split, 0, 0)
+        wsb = hip.conv3x3_workspace_bytes(d)
+        ok = hip.conv3x3_gnstat_ok(d, gnd)
+        plain = lambda o, k: hip.conv3x3(d, x.data_ptr(), w.data_ptr(), bias.data_ptr(), rv.data_ptr(), res.data_ptr(), o.data_ptr(), k.data_ptr(), k.numel())
+        fused = lambda o, k, gk: hip.conv3x3_gnstat(d, gnd, x.data_ptr(), w.data_ptr(), bias.data_ptr(), rv.data_ptr(), res.data_ptr(), o.data_ptr(),
+                                                   k.data_ptr(), k.numel(), gk.data_ptr(), gk.numel())
+    else:
+        x = h16(torch.randn(M, cin, generator=g)).half().to(DEV)
+        w = h16(torch.randn(cout, cin, generator=g) * cin ** -0.5).half().to(DEV)
+        d = hip.GemmDesc(M, cout, cin, cin, ldc, cout, epi, f * H * W, cout, 1.0, split, 0)
+        wsb = hip.gemm_workspace_bytes(d)
+        ok = hip.gemm_gnstat_ok(d, gnd)
+        plain = lambda o, k: hip.gemm(d, x.data_ptr(), w.data_ptr(), bias.data_ptr(), rv.data_ptr(), res.data_ptr(), o.data_ptr(), k.data_ptr(), k.numel())
+        fused = lambda o, k, gk: hip.gemm_gnstat(d, gnd, x.data_ptr(), w.data_ptr(), bias.data_ptr(), rv.data_ptr(), res.data_ptr(), o.data_ptr(),
+                                                k.data_ptr(), k.numel(), gk.data_ptr(), gk.numel())
+    assert wsb > 0 and ok and hip.groupnorm_prestat_ok(gnd)
+    outs = []
+    for mode in ("separate", "fused"):
+        o = torch.full((M, ldc), float("nan"), dtype=torch.float16, device=DEV)
+        y = torch.full((M, cout), float("nan"), dtype=torch.float16, device=DEV)
+        k, gk = ws(wsb), ws(hip.groupnorm_workspace_bytes(gnd))
+        if mode == "separate":
+            plain(o, k)
+            hip.groupnorm_silu(gnd, o.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), gk.data_ptr(), gk.numel())
+        else:
+            fused(o, k, gk)
+            hip.groupnorm_silu_prestat(gnd, o.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), gk.data_ptr(), gk.numel())
+        torch.cuda.synchronize()
+        outs.append((o[:, :cout].clone(), y.clone()))
+        assert torch.isnan(o[:, cout:].float()).all(), "wrote outside the output columns"
+    hip.set_igemm_variant(-1)
+    assert torch.equal(outs[0][0], outs[1][0]), "the producer's rows differ"
+    assert torch.equal(outs[0][1], outs[1][1]), "the norm's output differs"
+    # ... and the norm is the reference's GroupNorm of those rows
+    o32 = outs[1][0].float().cpu().reshape(b, f, H, W, cout).permute(0, 4, 1, 2, 3)
+    if cross:
+        ref = F.silu(O.group_norm_cross_frame(o32, gamma.cpu(), beta.cpu(), 32, 1e-5))
+    else:
+        x4 = o32.permute(0, 2, 1, 3, 4).reshape(n_img, cout, H, W)
+        ref = O.group_norm_per_frame(x4, gamma.cpu(), beta.cpu(), 32, 1e-6).reshape(b, f, cout, H, W).permute(0, 2, 1, 3, 4)
+    close(rows_to_5d(outs[1][1], b, cout, f, H, W), ref)
+
+
+def test_gnstat_refusals(hiplib):
+    """Loud refusals: a launch that is not split-K has no reduce pass to carry the statistics; a norm that runs as one launch has
+    no statistics pass to replace; mismatched rows."""
+    from rcdms_amd import hip
+    M, C = 10240, 640
+    d1 = hip.GemmDesc(M, C, 640, 640, C, 0, 1, 1, 0, 1.0, 1, 0)          # split_k = 1: no slabs
+    gnd = hip.GroupNormDesc(10, 1024, C, 32, C, C, 1e-6, 0)
+    assert not hip.gemm_gnstat_ok(d1, gnd)
+    d2 = hip.GemmDesc(M, C, 640, 640, C, 0, 1, 1, 0, 1.0, 2, 0)
+    assert hip.gemm_gnstat_ok(d2, gnd)
+    assert not hip.gemm_gnstat_ok(d2, hip.GroupNormDesc(10, 512, C, 32, C, C, 1e-6, 0))       # other row count
+    assert not hip.gemm_gnstat_ok(d2, hip.GroupNormDesc(10, 1024, C, 32, C + 8, C, 1e-6, 0))  # other row stride
+    small = hip.GroupNormDesc(10, 64, 1280, 32, 1280, 1280, 1e-6, 0)                         # single-launch norm (8x8 level)
+    assert not hip.groupnorm_prestat_ok(small)
+    x = torch.zeros(M, C, dtype=torch.float16, device=DEV)
+    k = ws(hip.gemm_workspace_bytes(d1) + 16)
+    with pytest.raises(hip.RcdmError):
+        hip.gemm_gnstat(d1, gnd, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, 0, x.data_ptr(), k.data_ptr(), k.numel(), k.data_ptr(), k.numel())
+    with pytest.raises(hip.RcdmError):
+        hip.groupnorm_silu_prestat(small, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), k.data_ptr(), k.numel())
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("b,f,H,W,C", [(2, 5, 32, 32, 640), (2, 5, 64, 64, 320), (1, 4, 24, 24, 960), (2, 5, 32, 32, 64)])
 def test_groupnorm_fold_is_bit_identical(hiplib, b, f, H, W, C):
     """Per-frame norms with many samples run as statistics + an apply kernel that finalises the groups itself (round 4); the
