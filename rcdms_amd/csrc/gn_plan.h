@@ -27,7 +27,10 @@ bool rcdm_gn_three_launch(const GnArgs& a);
 // Tail of a statistics block: per-thread column sums (sum[e], sq[e] of the thread's 8 columns over its rows) -> the G group
 // partials (count, mean, M2) of split `sp` of sample `s`.  part: dynamic LDS, (threads + CH) * 16 floats.  Column sums first
 // (CH * 16 values, each over the RPB row-threads, spread over the whole block), then the G groups: the one-step form (G
-// threads walking RPB * cg entries each) was a 120-read serial tail on 32 threads per block.
+// threads walking RPB * cg entries each) was a 120-read serial tail on 32 threads per block.  (The [thread][16] layout puts
+// a wave's ds accesses on two banks — SQ_LDS_BANK_CONFLICT several times SQ_ACTIVE_INST_LDS in the counters — but a
+// conflict-free value-major layout measured the same kernel times and the same step time, round 5: the tail is not on the
+// block's critical path, its one memory round trip is.)
 __device__ __forceinline__ void gn_block_partials(const GnArgs& p, float* part, int t, const float (&sum)[8], const float (&sq)[8],
                                                   int s, int sp, int nrows) {
 #pragma unroll
