@@ -238,9 +238,6 @@ void igemm_dma_kernel(const IgemmArgs p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rsrcA, (__attribute__((address_space(3))) void*)(sbase + (wave * AI + i) * 1024), 16, vo, 0, 0, 0);
     }
-#if defined(RCDM_DMA_ABLATE) && (RCDM_DMA_ABLATE & 1)   // upper bound of a weight operand that does not ride the LDS-DMA path: no weight pieces after a tile's first k-step (garbage results)
-    if (ks != 0) return;
-#endif
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int c = c0 + w_c[i];
