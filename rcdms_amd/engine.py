@@ -1182,8 +1182,9 @@ class UNetProgram:
                     nxt = (geo.n_img, geo.hw, groups)
                 else:
                     nxt = (geo.b, geo.f * geo.hw, groups) if next_resnet else None
-                if shared and si + 1 < len(stages) and stages[si + 1] == "t":
-                    nxt = None   # (the shared-prefix transformer norms half the rows)
+                if si + 1 < len(stages) and (shared or geo.M >= CHAIN_MIN_ROWS):
+                    nxt = None   # (the shared-prefix transformer norms half the rows; at the chain kernels' row count the
+                                 #  norm in front of a transformer / motion module is a statistics-only launch)
                 if st == "r":
                     pr = pb + f"resnets.{j}."
                     if shared:
