@@ -178,6 +178,7 @@ typedef struct {
   int32_t pad_after_only; /* 0: padding 1 on every side (default).  1: zero rows/columns only AFTER the image —
                            * diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) then a stride-2 conv (VAE encoder) */
   int32_t dup_rows;       /* as rcdm_gemm_desc.dup_rows */
+  int32_t c_in2, lda2;    /* rcdm_conv3x3_add1x1 only (0 otherwise): channels and row stride of the second input */
 } rcdm_conv3x3_desc;
 
 size_t rcdm_conv3x3_workspace_bytes(const rcdm_conv3x3_desc* d);
@@ -185,6 +186,17 @@ int rcdm_conv3x3_up2_supported(const rcdm_conv3x3_desc* d);   /* 1 | 0, d->upsam
 int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, const float* bias,
                  const float* rowvec, const void* residual, void* out, void* workspace,
                  size_t workspace_bytes, void* stream);
+/* conv3x3(in) + conv1x1(in2) accumulated in ONE implicit GEMM over K = 9 c_in + c_in2.   replaces the tail of
+ *   ResnetBlock3D.forward for c_in != c_out, resnet.py:205-212: conv2(hidden_states) + conv_shortcut(input_tensor)
+ *   (the sum is formed in the fp32 accumulators; the stand-alone shortcut launch, its f16 output and the residual read
+ *   of it are gone).  in2: [rows of `out`][lda2] f16, c_in2 channels used — row m of in2 is output pixel m, so stride 1,
+ *   upsample 0, no pad_after_only.  W f16 [c_out][9*c_in + c_in2]: the rcdm_conv3x3 layout followed by the 1x1 weight's
+ *   [c_out][c_in2] columns; bias = the sum of the two biases.  c_in % 64 == 0 and c_in2 % 64 == 0 (whole k-steps).
+ *   Everything else (epilogue flags, residual, split_k, workspace query with the same descriptor) as rcdm_conv3x3;
+ *   rcdm_conv3x3 / rcdm_conv3x3_gnstat themselves return RCDM_EINVAL for a descriptor with c_in2 != 0. */
+int rcdm_conv3x3_add1x1(const rcdm_conv3x3_desc* d, const void* in, const void* in2, const void* W, const float* bias,
+                        const float* rowvec, const void* residual, void* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm (+SiLU).  replaces torch.nn.GroupNorm applied to the 5-D tensor — statistics over
@@ -223,6 +235,10 @@ int rcdm_conv3x3_gnstat_ok(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc
 int rcdm_conv3x3_gnstat(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn, const void* in, const void* W,
                         const float* bias, const float* rowvec, const void* residual, void* out, void* workspace,
                         size_t workspace_bytes, void* gn_workspace, size_t gn_workspace_bytes, void* stream);
+int rcdm_conv3x3_add1x1_gnstat(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn, const void* in, const void* in2,
+                               const void* W, const float* bias, const float* rowvec, const void* residual, void* out,
+                               void* workspace, size_t workspace_bytes, void* gn_workspace, size_t gn_workspace_bytes,
+                               void* stream);   /* rcdm_conv3x3_add1x1 with the statistics-carrying reduce (rcdm_conv3x3_gnstat_ok) */
 /* finalize + apply only: the partial statistics are already in `workspace` (left there by a *_gnstat call with this
  * descriptor).  rcdm_groupnorm_prestat_ok: 1 when this descriptor's norm has a statistics pass to replace (three-launch
  * form; the smallest tensors run as one launch). */

@@ -176,6 +176,7 @@ void igemm_dma_kernel(const IgemmArgs p) {
 
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(TAPS == 9 ? p.A2 : p.A), 0, 0x7FFFFFFF, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   const int Hv = p.Hi << p.up, Wv = p.Wi << p.up;
 
@@ -220,8 +221,17 @@ void igemm_dma_kernel(const IgemmArgs p) {
       kci = ks / 9;
       tap = ks - kci * 9;
     }
+    // second input (IgemmArgs::A2, conv launches only): the k-steps from nk1 on are a tenth "tap" — the output pixel itself
+    // in another tensor with its own row stride and channel count, against W columns 9 Cin + c
+    const bool s2 = TAPS == 9 && ks >= p.nk1;   // (wave-uniform)
+    if (s2) {
+      kci = ks - p.nk1;
+      tap = 9;
+    }
     const int c0 = kci * BK;
-    const int dy = tap / 3, dx = tap - dy * 3;
+    const int dy = s2 ? 1 : tap / 3, dx = s2 ? 1 : tap - dy * 3;
+    const int cin = s2 ? p.Cin2 : p.Cin;
+    const unsigned lda = (unsigned)(s2 ? p.lda2 : p.lda);
     char* sbase = smem + stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
@@ -231,17 +241,21 @@ void igemm_dma_kernel(const IgemmArgs p) {
         vo = (c < p.Cin && a_off[i] != OOB) ? a_off[i] + (unsigned)c * 2u : OOB;
       } else {
         const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-        const bool ok = (c < p.Cin) && ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+        const bool ok = (c < cin) && ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
         const int sy = iy >> p.up, sx = ix >> p.up;
-        vo = ok ? ((unsigned)((a_img[i] * p.Hi + sy) * p.Wi + sx) * (unsigned)p.lda + (unsigned)c) * 2u : OOB;
+        vo = ok ? ((unsigned)((a_img[i] * p.Hi + sy) * p.Wi + sx) * lda + (unsigned)c) * 2u : OOB;
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrcA, (__attribute__((address_space(3))) void*)(sbase + (wave * AI + i) * 1024), 16, vo, 0, 0, 0);
+      if (TAPS == 9 && s2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrcA2, (__attribute__((address_space(3))) void*)(sbase + (wave * AI + i) * 1024), 16, vo, 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrcA, (__attribute__((address_space(3))) void*)(sbase + (wave * AI + i) * 1024), 16, vo, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int c = c0 + w_c[i];
-      const unsigned vo = (c < p.Cin && w_off[i] != OOB)
+      const unsigned vo = (c < cin && w_off[i] != OOB)
                               ? w_off[i] + ((unsigned)tap * (unsigned)p.Cin + (unsigned)c) * 2u : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rsrcW, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave * BI + i) * 1024), 16, vo, 0, 0, 0);
@@ -867,6 +881,9 @@ int num_cus() {
 
 // Split-K for the ping-pong kernel: its tiles are big, so shapes with fewer tiles than CUs (M = 10240 / 2560 rows with
 // N = 640 / 1280) are cut along K until one round of the chip is full; a slice keeps >= 16 k-steps.
+// taps of a launch: 1 (GEMM), 9 (conv3x3), 4 (phase form); the W row holds taps * Cin columns (+ Cin2 of a second input)
+inline int taps_of(const IgemmArgs& a) { return (a.Ktot - a.Cin2) / a.Cin; }
+
 int pp_splits(int tiles, int nk) {
   int s = num_cus() / (tiles > 0 ? tiles : 1);
   if (s > nk / 16) s = nk / 16;
@@ -881,7 +898,7 @@ int pp_splits(int tiles, int nk) {
 // with N <= 960 (qkv 1.13x, feed-forward out 1.12x).  The K = 640 / 1280 GEMMs of the 32x32 / 16x16 levels stay on the
 // two-blocks-per-CU kernel, whose second block hides the epilogue.  Returns the shape index or -1.
 int pick_pp(const IgemmArgs& a) {
-  const int taps = a.Ktot / a.Cin;
+  const int taps = taps_of(a);
   const int nk = (a.Cin + BK - 1) / BK * taps;
   if (a.M < 2048 || a.N < 256) return -1;
   if (taps == 1) {
@@ -924,7 +941,7 @@ bool pick_16(const IgemmArgs& a) {
     mode = e ? atoi(e) : 1;
   }
   if (!mode) return false;
-  const int taps = a.Ktot / a.Cin;
+  const int taps = taps_of(a);
   if (taps == 1) {
     // plain projections (no epilogue work: the staged halfs are copied out) that split into whole rounds of 160x160 tiles:
     // the cross-attention queries of the 32x32 level and of the shared-prefix half batch (tools/autotune.py: 17.3 -> 13.8 us)
@@ -1016,7 +1033,7 @@ const ShapeRule* find_shape_rule(const IgemmArgs& a) {
     n_env = n;
   }
   if (a.ph_rows) return nullptr;
-  const int taps = a.Ktot / a.Cin;
+  const int taps = taps_of(a);
   auto fits = [&](const ShapeRule& r) {
     if (r.taps != taps || r.M != a.M || r.N != a.N || r.Cin != a.Cin) return false;
     if (a.stat_out && !is_dma(r.variant)) return false;
@@ -1055,7 +1072,7 @@ int pick_variant(const IgemmArgs& a) {
   // without a 128x128 tile (8x8 / 16x16 levels, context K/V projections) run as 64x64 or 128x64 tiles so that several
   // blocks per CU keep more DMA in flight; N = 320 / 960 (half a 128-wide tile wasted) with a short K take 128x64;
   // the deep-K convs of the 32x32 / 16x16 levels take 256x256.
-  const int nk = (a.Cin + BK - 1) / BK * (a.Ktot / a.Cin);
+  const int nk = (a.Cin + BK - 1) / BK * taps_of(a) + (a.Cin2 + BK - 1) / BK;
   if (a.Ktot != a.Cin) {
     if (a.N <= 64) return 5;  // conv_out (4 -> 8 channels): half the weight tile of 128x128 is padding (51 -> 28 us)
     return 1;   // (the 256x256 LDS-DMA tile's conv instantiation spills 48 B: only when forced; the ping-pong 256x256 tile covers its shapes)
@@ -1101,8 +1118,13 @@ int fill_common(IgemmArgs& a, int requested_split, int* variant_out = nullptr) {
   a.tilesM = (a.M + tc.bm - 1) / tc.bm;
   a.tilesN = (a.N + tc.bn - 1) / tc.bn;
   a.kc = (a.Cin + BK - 1) / BK;
-  const int taps = a.Ktot / a.Cin;
+  const int taps = taps_of(a);
   a.nk = taps * a.kc;
+  a.nk1 = kNoSeg2;
+  if (a.Cin2 > 0) {          // second input: its k-steps follow the nine taps' (from_conv: Cin and Cin2 are multiples of BK)
+    a.nk1 = a.nk;
+    a.nk += a.Cin2 / BK;
+  }
   int s;
   const ShapeRule* rule = (g_force_variant == 99 && requested_split <= 0) ? find_shape_rule(a) : nullptr;
   if (rule && rule->split > 0) {
@@ -1315,6 +1337,13 @@ int from_conv(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
   a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.ldt = d->ldt;
   a.rows_per_sample = d->rows_per_sample; a.epi = d->epilogue; a.out_scale = d->out_scale;
   a.dup = (long long)d->dup_rows * d->ldc;
+  if (d->c_in2 < 0) return RCDM_EINVAL;
+  if (d->c_in2 > 0) {   // rcdm_conv3x3_add1x1: a 1x1 convolution of a second input in the same accumulators
+    if (d->stride != 1 || d->upsample || d->pad_after_only) return RCDM_ESHAPE;
+    if ((d->c_in % BK) || (d->c_in2 % BK) || (d->lda2 & 7) || d->lda2 < d->c_in2) return RCDM_ESHAPE;
+    if ((size_t)a.M * (size_t)d->lda2 * 2 >= 0x7FFFFFFFull) return RCDM_ESHAPE;
+    a.Cin2 = d->c_in2; a.lda2 = d->lda2; a.Ktot += d->c_in2;
+  }
   return RCDM_OK;
 }
 
@@ -1362,6 +1391,29 @@ int plan_up2(const rcdm_conv3x3_desc* d, IgemmArgs& a) {
   a.nk_per_split = (a.nk + s - 1) / s;
   a.splits = (a.nk + a.nk_per_split - 1) / a.nk_per_split;
   return best;
+}
+
+// the plain (upsample 0 | 1) conv launch behind rcdm_conv3x3 / _add1x1 / _gnstat / _add1x1_gnstat; gn: the norm whose
+// partial statistics the split-K reduce leaves (nullptr: none)
+int conv_launch(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn, const void* in, const void* in2, const void* W,
+                const float* bias, const float* rowvec, const void* residual, void* out, void* workspace,
+                size_t workspace_bytes, void* gn_workspace, size_t gn_workspace_bytes, void* stream) {
+  IgemmArgs a{};
+  int rc = from_conv(d, a);
+  if (rc) return rc;
+  a.A = (const f16*)in; a.W = (const f16*)W; a.bias = bias; a.rowvec = rowvec;
+  a.res = (const f16*)residual; a.out = (f16*)out;
+  a.A2 = (const f16*)in2;
+  rc = check_common(a);
+  if (rc) return rc;
+  if (a.epi & RCDM_EPI_GEGLU) return RCDM_ESHAPE;
+  int variant = 0;
+  fill_common(a, d->split_k, &variant);
+  if (gn) {
+    rc = attach_gnstat(a, gn, gn_workspace, gn_workspace_bytes, true);
+    if (rc) return rc;
+  }
+  return launch<9>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // namespace
@@ -1554,16 +1606,15 @@ int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, cons
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return rcdm_check_launch();
   }
-  int rc = from_conv(d, a);
-  if (rc) return rc;
-  a.A = (const f16*)in; a.W = (const f16*)W; a.bias = bias; a.rowvec = rowvec;
-  a.res = (const f16*)residual; a.out = (f16*)out;
-  rc = check_common(a);
-  if (rc) return rc;
-  if (a.epi & RCDM_EPI_GEGLU) return RCDM_ESHAPE;
-  int variant = 0;
-  fill_common(a, d->split_k, &variant);
-  return launch<9>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);
+  if (d->c_in2) return RCDM_EINVAL;   // (a descriptor of rcdm_conv3x3_add1x1)
+  return conv_launch(d, nullptr, in, nullptr, W, bias, rowvec, residual, out, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+int rcdm_conv3x3_add1x1(const rcdm_conv3x3_desc* d, const void* in, const void* in2, const void* W, const float* bias,
+                        const float* rowvec, const void* residual, void* out, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  if (!d || d->upsample == 2 || d->c_in2 <= 0 || !in2) return RCDM_EINVAL;
+  return conv_launch(d, nullptr, in, in2, W, bias, rowvec, residual, out, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
 int rcdm_conv3x3_gnstat_ok(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn) {
@@ -1577,21 +1628,20 @@ int rcdm_conv3x3_gnstat_ok(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc
 int rcdm_conv3x3_gnstat(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn, const void* in, const void* W,
                         const float* bias, const float* rowvec, const void* residual, void* out, void* workspace,
                         size_t workspace_bytes, void* gn_workspace, size_t gn_workspace_bytes, void* stream) {
-  if (!d) return RCDM_EINVAL;
+  if (!d || !gn) return RCDM_EINVAL;
   if (d->upsample == 2) return RCDM_ESHAPE;
-  IgemmArgs a{};
-  int rc = from_conv(d, a);
-  if (rc) return rc;
-  a.A = (const f16*)in; a.W = (const f16*)W; a.bias = bias; a.rowvec = rowvec;
-  a.res = (const f16*)residual; a.out = (f16*)out;
-  rc = check_common(a);
-  if (rc) return rc;
-  if (a.epi & RCDM_EPI_GEGLU) return RCDM_ESHAPE;
-  int variant = 0;
-  fill_common(a, d->split_k, &variant);
-  rc = attach_gnstat(a, gn, gn_workspace, gn_workspace_bytes, true);
-  if (rc) return rc;
-  return launch<9>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);
+  if (d->c_in2) return RCDM_EINVAL;
+  return conv_launch(d, gn, in, nullptr, W, bias, rowvec, residual, out, workspace, workspace_bytes, gn_workspace,
+                     gn_workspace_bytes, stream);
+}
+
+int rcdm_conv3x3_add1x1_gnstat(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn, const void* in, const void* in2,
+                               const void* W, const float* bias, const float* rowvec, const void* residual, void* out,
+                               void* workspace, size_t workspace_bytes, void* gn_workspace, size_t gn_workspace_bytes,
+                               void* stream) {
+  if (!d || !gn || d->upsample == 2 || d->c_in2 <= 0 || !in2) return RCDM_EINVAL;
+  return conv_launch(d, gn, in, in2, W, bias, rowvec, residual, out, workspace, workspace_bytes, gn_workspace,
+                     gn_workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
 
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(TAPS == 9 ? p.A2 : p.A), 0, 0x7FFFFFFF, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   const int Hv = p.Hi << p.up, Wv = p.Wi << p.up;
   const int lrow = lane >> 3, lch = lane & 7;
@@ -93,12 +94,21 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
   auto issue = [&](int g, int stage) __attribute__((always_inline)) {
     const int ks = ks_begin + g;
     int tap = 0, kci = ks;
+    // second input (IgemmArgs::A2, conv launches only): the k-steps from nk1 on are a tenth "tap" — the output pixel itself
+    // (dy = dx = 1 from the padded origin) in ANOTHER tensor with its own row stride and channel count; W column 9 Cin + c
+    const bool s2 = TAPS == 9 && ks >= p.nk1;
     if (TAPS != 1) {  // channel chunk outer, tap inner
       kci = ks / 9;
       tap = ks - kci * 9;
+      if (s2) {
+        kci = ks - p.nk1;
+        tap = 9;
+      }
     }
     const int c0 = kci * BK;
-    const int dy = tap / 3, dx = tap - dy * 3;
+    const int dy = s2 ? 1 : tap / 3, dx = s2 ? 1 : tap - dy * 3;
+    const int cin = s2 ? p.Cin2 : p.Cin;
+    const unsigned lda = (unsigned)(s2 ? p.lda2 : p.lda);
     char* sbase = smem + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -108,13 +118,17 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
         vo = (c < p.Cin && a_off[i] != OOB) ? a_off[i] + (unsigned)c * 2u : OOB;
       } else {
         const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-        const bool ok = (c < p.Cin) && ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+        const bool ok = (c < cin) && ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
         const int sy = iy >> p.up, sx = ix >> p.up;
-        const unsigned off = ((unsigned)(a_img[i] + sy * p.Wi + sx) * (unsigned)p.lda + (unsigned)c) * 2u;
+        const unsigned off = ((unsigned)(a_img[i] + sy * p.Wi + sx) * lda + (unsigned)c) * 2u;
         vo = ok ? off : OOB;
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrcA, (__attribute__((address_space(3))) void*)(sbase + (wave * NP + i) * 1024), 16, vo, 0, 0, 0);
+      if (TAPS == 9 && s2)   // (wave-uniform: ks is)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrcA2, (__attribute__((address_space(3))) void*)(sbase + (wave * NP + i) * 1024), 16, vo, 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrcA, (__attribute__((address_space(3))) void*)(sbase + (wave * NP + i) * 1024), 16, vo, 0, 0, 0);
     }
 #if RCDM_I16_ABLATE & 16   // upper bound of a direct-to-VGPR weight operand: no weight DMA after the first stage
     if (g > 0) return;
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int c = c0 + w_c[i];
-      const unsigned vo = (c < p.Cin && w_off[i] != OOB)
+      const unsigned vo = (c < cin && w_off[i] != OOB)
                               ? w_off[i] + ((unsigned)tap * (unsigned)p.Cin + (unsigned)c) * 2u : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rsrcW, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave * NP + i) * 1024), 16, vo, 0, 0, 0);

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
 
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(TAPS == 9 ? p.A2 : p.A), 0, 0x7FFFFFFF, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   const int Hv = p.Hi << p.up, Wv = p.Wi << p.up;
 
@@ -147,6 +148,10 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
     if (TAPS != 1) {  // channel chunk outer, tap inner (the nine windows of one 64-channel slab re-hit L2)
       kci = ks / TAPS;
       tap = ks - kci * TAPS;
+      if (TAPS == 9 && ks >= p.nk1) {   // second input (IgemmArgs::A2): a tenth "tap" = the output pixel itself in another tensor
+        kci = ks - p.nk1;
+        tap = 9;
+      }
     }
     c0 = kci * BK;
   };
@@ -154,7 +159,10 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
     const int slot = ks & 1;
     int c0, tap;
     kpos(ks, c0, tap);
-    const int dy = TAPS == 4 ? tap >> 1 : tap / 3, dx = TAPS == 4 ? tap & 1 : tap - dy * 3;
+    const bool s2 = TAPS == 9 && tap == 9;   // (wave-uniform)
+    const int dy = s2 ? 1 : TAPS == 4 ? tap >> 1 : tap / 3, dx = s2 ? 1 : TAPS == 4 ? tap & 1 : tap - dy * 3;
+    const int cin = s2 ? p.Cin2 : p.Cin;
+    const unsigned lda = (unsigned)(s2 ? p.lda2 : p.lda);
 #if defined(RCDM_PP_ABLATE) && (RCDM_PP_ABLATE & 8)   // bound of a halo-staged pixel tile: the pixel pieces of 2 taps in 9 only (garbage results)
     if (TAPS != 1 && tap >= 2) return;
 #endif
@@ -166,25 +174,31 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs p) {
         vo = (c < p.Cin && a_off[i] != OOB) ? a_off[i] + (unsigned)c * 2u : OOB;
       } else {
         const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-        const bool ok = (c < p.Cin) && ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+        const bool ok = (c < cin) && ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
         const int sy = iy >> p.up, sx = ix >> p.up;
         // computed unconditionally (a select, not a branch: no address is dereferenced here)
-        const unsigned off = ((unsigned)(a_img[i] + sy * p.Wi + sx) * (unsigned)p.lda + (unsigned)c) * 2u;
+        const unsigned off = ((unsigned)(a_img[i] + sy * p.Wi + sx) * lda + (unsigned)c) * 2u;
         vo = ok ? off : OOB;
       }
-      if (a_lds[i] >= 0)  // wave-uniform: the waves whose last piece does not exist issue one DMA fewer
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrcA, (__attribute__((address_space(3))) void*)(smem + slot * A_BYTES + a_lds[i]), 16, vo, 0, 0, RCDM_PP_AAUX);
+      if (a_lds[i] >= 0) {  // wave-uniform: the waves whose last piece does not exist issue one DMA fewer
+        if (TAPS == 9 && s2)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              rsrcA2, (__attribute__((address_space(3))) void*)(smem + slot * A_BYTES + a_lds[i]), 16, vo, 0, 0, RCDM_PP_AAUX);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              rsrcA, (__attribute__((address_space(3))) void*)(smem + slot * A_BYTES + a_lds[i]), 16, vo, 0, 0, RCDM_PP_AAUX);
+      }
     }
   };
   auto issue_w = [&](int ks) __attribute__((always_inline)) {
     const int slot = ks % 3;
     int c0, tap;
     kpos(ks, c0, tap);
+    const int cin = (TAPS == 9 && tap == 9) ? p.Cin2 : p.Cin;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       const int c = c0 + w_c[i];
-      const unsigned vo = (c < p.Cin && w_off[i] != OOB)
+      const unsigned vo = (c < cin && w_off[i] != OOB)
                               ? w_off[i] + ((unsigned)tap * (unsigned)p.Cin + (unsigned)c) * 2u : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rsrcW, (__attribute__((address_space(3))) void*)(smem + slot * W_BYTES + w_lds[i]), 16, vo, 0, 0, RCDM_PP_WAUX);

@@ -55,7 +55,15 @@ struct IgemmArgs {
   // rcdm_conv3x3_gnstat; splitk_reduce_gn_kernel): the statistics geometry of gn_plan.h for the norm that reads `out` next
   float* gn_partial;            // null: plain reduce
   int gn_samples, gn_P, gn_G, gn_cg, gn_CH, gn_RPB, gn_splits, gn_rps;
+  // conv3x3 + a 1x1 convolution of a SECOND input accumulated into the same output (rcdm_conv3x3_add1x1: ResnetBlock3D's
+  // conv2(...) + conv_shortcut(input_tensor), resnet.py:205-212, as one implicit GEMM over K = 9 Cin + Cin2): the k-steps
+  // [nk1, nk) read A2 — row m of A2 is output pixel m (stride 1, no upsample) — against W columns 9 Cin + c, i.e. a tenth
+  // "tap" with its own tensor, row stride and channel count.  nk1 = INT_MAX: no second input.
+  const f16* A2;
+  int lda2, Cin2;
+  int nk1 = 0x7fffffff;         // (default member initialiser: `IgemmArgs a{}` must not switch the second input on)
 };
+constexpr int kNoSeg2 = 0x7fffffff;
 // output row of virtual row m of a phase launch (IgemmArgs::ph_rows): the (2y + a, 2x + b) pixel of the upsampled image
 __device__ __forceinline__ int phase_out_row(const IgemmArgs& p, int m) {
   const int ph = m / p.ph_rows, pm = m - ph * p.ph_rows;

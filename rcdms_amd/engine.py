@@ -221,7 +221,9 @@ def gemm_lnx_ok(M, N, K, lda, ldc, geglu=False, dup_rows=0):
 
 
 def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=None, rowvec=None, residual=None,
-                 scale=1.0, split_k=0, pad_after_only=0, dup_rows=0, gn=None):
+                 scale=1.0, split_k=0, pad_after_only=0, dup_rows=0, gn=None, x2=None):
+    """x2 (Rows of the output's row count): a second input whose 1x1 convolution is accumulated into the same output
+    (rcdm_conv3x3_add1x1); Wt then carries its [cout][x2.C] columns behind the nine taps'."""
     epi = 0
     if bias is not None:
         epi |= hip.EPI_BIAS
@@ -230,7 +232,8 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
     if residual is not None:
         epi |= hip.EPI_RESIDUAL
     d = hip.ConvDesc(n_img, H, W, cin, cout, stride, up, x.ld, out.ld, residual.ld if residual is not None else 0,
-                     epi, rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k, pad_after_only, dup_rows)
+                     epi, rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k, pad_after_only, dup_rows,
+                     x2.C if x2 is not None else 0, x2.ld if x2 is not None else 0)
     wsb = hip.conv3x3_workspace_bytes(d)
     ws = plan.scratch("splitk_ws", max(wsb, 256))
     bptr = bias.data_ptr() if bias is not None else 0
@@ -240,13 +243,22 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
 
     def op():
         rvp = (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0
+        rp = residual.ptr if residual is not None else 0
+        if x2 is not None:
+            if hand is not None:
+                hip.conv3x3_add1x1_gnstat(d, hand[0], x.ptr, x2.ptr, Wt.data_ptr(), bptr, rvp, rp, out.ptr, ws.ptr, ws.nbytes,
+                                          hand[1].ptr, hand[1].nbytes)
+            else:
+                hip.conv3x3_add1x1(d, x.ptr, x2.ptr, Wt.data_ptr(), bptr, rvp, rp, out.ptr, ws.ptr, ws.nbytes)
+            return
         if hand is not None:
-            hip.conv3x3_gnstat(d, hand[0], x.ptr, Wt.data_ptr(), bptr, rvp, residual.ptr if residual is not None else 0, out.ptr,
+            hip.conv3x3_gnstat(d, hand[0], x.ptr, Wt.data_ptr(), bptr, rvp, rp, out.ptr,
                                ws.ptr, ws.nbytes, hand[1].ptr, hand[1].nbytes)
             return
-        hip.conv3x3(d, x.ptr, Wt.data_ptr(), bptr, rvp, residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes)
+        hip.conv3x3(d, x.ptr, Wt.data_ptr(), bptr, rvp, rp, out.ptr, ws.ptr, ws.nbytes)
     n_before = len(plan.ops)
-    plan.add(op, f"conv3x3 {n_img}x{H}x{W} {cin}->{cout} s={stride} up={up} epi={epi}" + (" gnstat" if hand is not None else ""))
+    plan.add(op, f"conv3x3 {n_img}x{H}x{W} {cin}->{cout} s={stride} up={up} epi={epi}" + (f" add1x1={x2.C}" if x2 is not None else "")
+             + (" gnstat" if hand is not None else ""))
     if len(plan.ops) > n_before:
         plan.op_weights[len(plan.ops) - 1] = Wt
         if hand is not None:
@@ -255,6 +267,9 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
     plan.n_launch += 2 if wsb else 1
 
 
+# ResnetBlock3D's conv_shortcut folded into conv2's implicit GEMM (rcdm_conv3x3_add1x1); RCDM_SC_FOLD=0 keeps the separate
+# 1x1 GEMM + residual read (same-process A/B)
+SC_FOLD = os.environ.get("RCDM_SC_FOLD", "1") != "0"
 # Upsample3D's nearest-2x + conv3x3 as four 2x2 phase convolutions over the source grid (rcdm_conv3x3 upsample = 2: 4/9 of
 # the multiply-adds) wherever the library takes the shape; RCDM_UP2=0 keeps the upsample = 1 form (same-process A/B)
 UP2 = os.environ.get("RCDM_UP2", "1") != "0"
@@ -559,9 +574,15 @@ def pack_resnet(pk, p):
     w.g2, w.b2 = pk.vec(p + "norm2.weight"), pk.vec(p + "norm2.bias")
     w.conv1, w.cb1 = pk.conv3x3(p + "conv1.weight"), pk.vec(p + "conv1.bias")
     w.conv2, w.cb2 = pk.conv3x3(p + "conv2.weight"), pk.vec(p + "conv2.bias")
-    w.shortcut = None
+    w.shortcut = w.conv2sc = None
     if pk.has(p + "conv_shortcut.weight"):
         w.shortcut, w.sb = pk.mat_f16(p + "conv_shortcut.weight"), pk.vec(p + "conv_shortcut.bias")
+        if SC_FOLD and w.cin % 64 == 0 and w.cout % 64 == 0:
+            # conv2(h) + conv_shortcut(x) as ONE implicit GEMM over K = 9 cout + cin (rcdm_conv3x3_add1x1): the 1x1 weight's
+            # columns behind the nine taps' (a copy of the already rounded halfs), the two biases summed in fp32
+            w.conv2sc = torch.cat([w.conv2, w.shortcut], dim=1).contiguous()
+            w.cb2sc = (w.cb2 + w.sb).contiguous()
+            w.conv2 = w.shortcut = None   # (not read again: no second copy of the block's largest matrix)
     return w
 
 
@@ -730,6 +751,8 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
     a1 = plan.rows("norm", g.M, x.C)
     emit_groupnorm(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, True, a1, groups)   # (first: x may carry a producer's statistics)
     res = x
+    fold_sc = w.conv2sc is not None
+    assert not fold_sc or x.C == w.cin
     if w.shortcut is not None:
         res = plan.rows("res_sc", g.M, w.cout)
         emit_gemm(plan, x, w.shortcut, w.cout, w.cin, res, bias=w.sb)
@@ -738,6 +761,10 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
                  rowvec=(temb[0], temb[1], temb[2], g.f * g.hw), gn=(g.b, g.f * g.hw, groups))
     a2 = plan.rows("norm", g.M, w.cout)
     emit_groupnorm(plan, h1, g.b, g.f * g.hw, w.g2, w.b2, eps, True, a2, groups)
+    if fold_sc:   # (resnet.py:205-212 with a conv_shortcut: its 1x1 convolution of x rides in conv2's accumulators)
+        emit_conv3x3(plan, a2, g.n_img, g.H, g.W, w.conv2sc, w.cout, w.cout, out, bias=w.cb2sc, scale=out_scale,
+                     dup_rows=dup_rows, gn=out_gn, x2=x)
+        return
     emit_conv3x3(plan, a2, g.n_img, g.H, g.W, w.conv2, w.cout, w.cout, out, bias=w.cb2, residual=res, scale=out_scale,
                  dup_rows=dup_rows, gn=out_gn)
 

@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
                 ("upsample", C.c_int32), ("lda", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("epilogue", C.c_int32), ("rows_per_sample", C.c_int32), ("ldt", C.c_int32),
                 ("out_scale", C.c_float), ("split_k", C.c_int32), ("pad_after_only", C.c_int32),
-                ("dup_rows", C.c_int32)]
+                ("dup_rows", C.c_int32), ("c_in2", C.c_int32), ("lda2", C.c_int32)]
 
 
 class GroupNormDesc(C.Structure):
@@ -102,6 +102,8 @@ SYMBOLS = {
     "rcdm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_conv3x3_workspace_bytes": (_SZ, [C.POINTER(ConvDesc)]),
     "rcdm_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rcdm_conv3x3_add1x1": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rcdm_conv3x3_add1x1_gnstat": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
     "rcdm_groupnorm_workspace_bytes": (_SZ, [C.POINTER(GroupNormDesc)]),
     "rcdm_groupnorm_silu": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _SZ, _P]),
@@ -238,6 +240,11 @@ def conv3x3(desc, x, W, bias, rowvec, residual, out, ws_ptr=0, ws_bytes=0, strea
                                stream_ptr() if stream is None else stream), "rcdm_conv3x3")
 
 
+def conv3x3_add1x1(desc, x, x2, W, bias, rowvec, residual, out, ws_ptr=0, ws_bytes=0, stream=None):
+    _check(load().rcdm_conv3x3_add1x1(C.byref(desc), x, x2, W, bias, rowvec, residual, out, ws_ptr, ws_bytes,
+                                      stream_ptr() if stream is None else stream), "rcdm_conv3x3_add1x1")
+
+
 def groupnorm_workspace_bytes(desc):
     return load().rcdm_groupnorm_workspace_bytes(C.byref(desc))
 
@@ -272,6 +279,12 @@ def conv3x3_gnstat_ok(desc, gn):
 def conv3x3_gnstat(desc, gn, x, W, bias, rowvec, residual, out, ws_ptr, ws_bytes, gn_ws_ptr, gn_ws_bytes, stream=None):
     _check(load().rcdm_conv3x3_gnstat(C.byref(desc), C.byref(gn), x, W, bias, rowvec, residual, out, ws_ptr, ws_bytes, gn_ws_ptr,
                                       gn_ws_bytes, stream_ptr() if stream is None else stream), "rcdm_conv3x3_gnstat")
+
+
+def conv3x3_add1x1_gnstat(desc, gn, x, x2, W, bias, rowvec, residual, out, ws_ptr, ws_bytes, gn_ws_ptr, gn_ws_bytes, stream=None):
+    _check(load().rcdm_conv3x3_add1x1_gnstat(C.byref(desc), C.byref(gn), x, x2, W, bias, rowvec, residual, out, ws_ptr, ws_bytes,
+                                             gn_ws_ptr, gn_ws_bytes, stream_ptr() if stream is None else stream),
+           "rcdm_conv3x3_add1x1_gnstat")
 
 
 def groupnorm_stats(desc, x, stat, ws_ptr, ws_bytes, stream=None):

@@ -334,6 +334,74 @@ def test_conv3x3(hiplib, b, f, H, W, cin, cout, stride, up, split, variant):
     close(rows_to_5d(out, b, cout, f, Ho, Wo), ref)
 
 
+@pytest.mark.parametrize("b,f,H,W,cin,cin2,cout,split", [
+    (1, 2, 8, 8, 64, 128, 64, 1),        # the second input deeper than one tap
+    (2, 3, 10, 6, 128, 64, 72, 1),       # M tail, N tail, a padded second-input row stride
+    (2, 1, 8, 8, 320, 640, 320, 4),      # split-K: the second input's k-steps sit in the last slab
+    (2, 5, 16, 16, 128, 192, 320, 0),    # 2560 pixels: several tiles, heuristic split
+    (2, 5, 8, 8, 1280, 2560, 1280, 0),   # the 8x8-level up-block ResNet (conv2 + shortcut of the 2560-channel concat)
+])
+@pytest.mark.parametrize("variant", [-1, 1, 3, 5, 6, 7, 8, 9])
+def test_conv3x3_add1x1(hiplib, b, f, H, W, cin, cin2, cout, split, variant):
+    """rcdm_conv3x3_add1x1: conv3x3(x) + conv1x1(x2) in one implicit GEMM (ResnetBlock3D conv2 + conv_shortcut,
+    resnet.py:205-212) against the two fp32 convolutions, on every tile family, with split-K and the fused epilogue."""
+    from rcdms_amd import hip
+    if variant == -1 and cin < 1280:
+        pytest.skip("heuristic pick: production shape only")
+    if variant != -1 and cin >= 1280 and variant not in (1, 8, 9):
+        pytest.skip("production shape: its own tile families only")
+    g = torch.Generator().manual_seed(77 + cin + cin2 + cout)
+    x = h16(torch.randn(b, cin, f, H, W, generator=g))
+    x2 = h16(torch.randn(b, cin2, f, H, W, generator=g))
+    w = h16(torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
+    w2 = h16(torch.randn(cout, cin2, generator=g) * cin2 ** -0.5)
+    bias = torch.randn(cout, generator=g)
+    temb = torch.randn(b, cout, generator=g)
+    res = h16(torch.randn(b, cout, f, H, W, generator=g))
+    ref = (O.conv_frames(x, w, bias, stride=1, padding=1) + torch.einsum("oc,bcfhw->bofhw", w2, x2)
+           + temb[:, :, None, None, None] + res) * 0.5
+    lda, lda2 = cin + 8, cin2 + 16
+    xd, x2d, rd = rows_from_5d(x, lda), rows_from_5d(x2, lda2), rows_from_5d(res)
+    wp = torch.empty(cout, 9 * cin, dtype=torch.float16, device=DEV)
+    w32 = w.to(DEV)
+    hip.pack_conv3x3(w32.data_ptr(), cout, cin, cin, wp.data_ptr())
+    wk = torch.cat([wp, w2.half().to(DEV)], dim=1).contiguous()
+    out = torch.full((b * f * H * W, cout), float("nan"), dtype=torch.float16, device=DEV)
+    d = hip.ConvDesc(b * f, H, W, cin, cout, 1, 0, lda, cout, cout, hip.EPI_BIAS | hip.EPI_ROWVEC | hip.EPI_RESIDUAL,
+                     f * H * W, cout, 0.5, split, 0, 0, cin2, lda2)
+    bd, td = bias.to(DEV), temb.to(DEV)
+    hip.set_igemm_variant(variant)
+    try:
+        wsb = ws(hip.conv3x3_workspace_bytes(d))
+        hip.conv3x3_add1x1(d, xd.data_ptr(), x2d.data_ptr(), wk.data_ptr(), bd.data_ptr(), td.data_ptr(), rd.data_ptr(),
+                           out.data_ptr(), wsb.data_ptr(), wsb.numel())
+        torch.cuda.synchronize()
+        # the plain entry point refuses a descriptor that names a second input (it has no pointer for it)
+        with pytest.raises(hip.RcdmError):
+            hip.conv3x3(d, xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), td.data_ptr(), rd.data_ptr(), out.data_ptr(),
+                        wsb.data_ptr(), wsb.numel())
+    finally:
+        hip.set_igemm_variant(-1)
+    close(rows_to_5d(out, b, cout, f, H, W), ref)
+
+
+def test_conv3x3_add1x1_refusals(hiplib):
+    """The second input needs stride 1, no upsample, whole 64-channel k-steps on both inputs and a pointer."""
+    from rcdms_amd import hip
+    x = torch.zeros(64, dtype=torch.float16, device=DEV)
+    p = x.data_ptr()
+    for bad in (hip.ConvDesc(2, 8, 8, 64, 64, 2, 0, 64, 64, 0, 0, 1, 0, 1.0, 0, 0, 0, 64, 64),      # stride 2
+                hip.ConvDesc(2, 8, 8, 64, 64, 1, 1, 64, 64, 0, 0, 1, 0, 1.0, 0, 0, 0, 64, 64),      # upsample
+                hip.ConvDesc(2, 8, 8, 72, 64, 1, 0, 72, 64, 0, 0, 1, 0, 1.0, 0, 0, 0, 64, 64),      # c_in % 64
+                hip.ConvDesc(2, 8, 8, 64, 64, 1, 0, 64, 64, 0, 0, 1, 0, 1.0, 0, 0, 0, 72, 72),      # c_in2 % 64
+                hip.ConvDesc(2, 8, 8, 64, 64, 1, 0, 64, 64, 0, 0, 1, 0, 1.0, 0, 0, 0, 64, 32)):     # lda2 < c_in2
+        with pytest.raises(hip.RcdmError):
+            hip.conv3x3_add1x1(bad, p, p, p, 0, 0, 0, p, 0, 0)
+    ok = hip.ConvDesc(2, 8, 8, 64, 64, 1, 0, 64, 64, 0, 0, 1, 0, 1.0, 0, 0, 0, 64, 64)
+    with pytest.raises(hip.RcdmError):
+        hip.conv3x3_add1x1(ok, p, 0, p, 0, 0, 0, p, 0, 0)     # no second input
+
+
 @pytest.mark.parametrize("n_img,H,W,cin,cout,variant,split", [
     (5, 16, 16, 64, 96, 6, 0),       # 1280 source pixels = 8 tiles of 160 rows per phase; N tail (96 of a 320-wide tile)
     (5, 16, 16, 128, 256, 7, 0),     # 160x256 tiles
