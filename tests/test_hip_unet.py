@@ -122,6 +122,21 @@ def test_full_unet_skewed_weights_vs_reference(hiplib):
         check(y, g["y"], 7e-3, 1e-2, f"unet_full_{hw}_skewed")
 
 
+def test_full_unet_plan_folds_the_resnet_shortcuts(full_unet):
+    """The launch plan of the full-width UNet carries every ResnetBlock3D conv_shortcut inside conv2's implicit GEMM
+    (rcdm_conv3x3_add1x1, resnet.py:205-212): 14 blocks change their width, none of them launches a stand-alone 1x1
+    projection or reads a shortcut buffer back.  (The goldens above run through exactly this plan.)"""
+    full_unet(torch.zeros(2, 9, 5, 32, 32, device=DEV), torch.tensor(981), torch.zeros(10, 85, 768, device=DEV), return_dict=False)
+    prog = full_unet.program(2, 5, 32, 32, 85)
+    tags = prog.plan.tags
+    folded = [t for t in tags if " add1x1=" in t]
+    assert len(folded) == 14, folded
+    assert "res_sc" not in prog.plan.bufs
+    widths = sorted(int(t.split("add1x1=")[1].split()[0]) for t in folded)
+    # down blocks 1, 2: 320, 640; up blocks (skip concat): 3 x 2560 | 2560, 2560, 1920 | 1920, 1280, 960 | 960, 640, 640
+    assert widths == sorted([320, 640] + [2560] * 5 + [1920] * 2 + [1280] + [960] * 2 + [640] * 2), widths
+
+
 @pytest.mark.parametrize("hw", [32, 64])
 def test_full_unet_eps_along_trajectory(full_unet, hw):
     """eps-parity at mid / late points of the denoising trajectory: the HIP UNet's raw output at the REFERENCE
