@@ -144,6 +144,10 @@ def parse_args(argv=None):
                     help="latency mode (not the headline metric): two GPUs per story, one CFG half each, noise predictions "
                          "all-gathered over RCCL inside the step graph; with --gpus 1 ONE half is timed against a one-rank "
                          "communicator (what a rank of a pair does per step, the exchange being a local copy)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: every rank runs on device 0 and the process group is gloo — the N > 1 code path of this "
+                         "file (per-rank build, weight broadcast, sharded stories, barrier / max-over-ranks timing) on a box "
+                         "with ONE GPU; the printed line is marked and is not a measurement")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="TEST ONLY: exercise the launch / barrier / max-over-ranks harness on CPU (gloo) with a sleep "
                          "in place of the denoising loop; the printed line is marked data=stub and is not a measurement")
@@ -156,7 +160,7 @@ def spawn_ranks(a, argv):
     torch.distributed.run on 127.0.0.1 so every rank sees RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
     import socket
     import subprocess
-    if not a.stub_cpu:
+    if not a.stub_cpu and not a.share_gpu:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < a.gpus:
             raise SystemExit(f"bench.py: {a.gpus} ranks requested (--gpus {a.gpus}) but {have} device(s) visible; "
@@ -249,6 +253,8 @@ def main(argv=None):
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if a.share_gpu:
+        local_rank = 0      # (test harness: all ranks on one device)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
@@ -257,7 +263,10 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with stdout_to_stderr():
-            dist.init_process_group("nccl", device_id=dev)
+            if a.share_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
             dist.barrier()      # brings the RCCL communicator up here, banner and all
 
     import __graft_entry__
@@ -311,7 +320,8 @@ def main(argv=None):
         ev1.record(sp)
         gpu_ms[0] += ev0.elapsed_ms(ev1)
 
-    dt, per_rank = timed_passes(timed_pass, a.steps, dist if dist_on else None, torch.cuda.synchronize, dev)
+    dt, per_rank = timed_passes(timed_pass, a.steps, dist if dist_on else None, torch.cuda.synchronize,
+                                torch.device("cpu") if a.share_gpu else dev)   # (gloo gathers host tensors)
 
     frames = 5 * S * a.steps * units
     value = frames / dt
@@ -364,6 +374,8 @@ def main(argv=None):
             out["rccl_version"] = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, a.latent, a.ctx_len, T)
+    if a.share_gpu:
+        out["data"] = "INVALID (--share-gpu harness test: every rank on ONE device over gloo; not a measurement)"
     if os.environ.get("RCDM_DROP_OPS"):
         out["data"] = "INVALID (RCDM_DROP_OPS set: ops left out of the plan, timing experiment only)"
     if rank == 0:

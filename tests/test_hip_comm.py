@@ -118,3 +118,25 @@ def test_cfg_split_needs_guidance(hiplib):
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
     with pytest.raises(ValueError, match="guidance"):
         DenoiseLoop(m, 1, 5, 16, 16, 13, 1.0, sched, 2, cfg_split=CfgSplit(0, lambda *a: None))
+
+
+def test_bench_two_ranks_share_one_gpu(hiplib):
+    """The N > 1 code path of bench.py end to end on a one-GPU box (`--share-gpu`: both ranks on device 0, gloo instead of
+    RCCL): per-rank build barrier, the full-width UNet built on every rank, broadcast_module of rank 0's 1286 tensors (GPU
+    tensors, f16 wire), one story per rank with its own seed, the barrier / max-over-ranks timing and the gathered device
+    list.  The line is marked INVALID — it only proves that the path the driver's 8-GPU run takes executes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "0",
+                        "--ddim-steps", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and len(out["per_rank_ms"]) == 2 and len(out["devices"]) == 2
+    assert out["data"].startswith("INVALID (--share-gpu")
+    assert out["config"]["parallelism"] == "story-replicas x2" and out["scaling"] == "weak"
+    # value = the frames of BOTH ranks over the slower rank's time
+    assert abs(out["value"] - 5 * 1 * 1 * 2 / (out["ms_per_step"] * 1e-3)) < 1e-3 * out["value"]
