@@ -572,6 +572,8 @@ def test_groupnorm(hiplib, b, f, H, W, C, cross, silu):
     ("conv", 1, 5, 24, 24, 64, 960, False, 2, 1),      # one sample per image, 576 rows each
     ("gemm", 2, 5, 32, 32, 1280, 640, False, 4, -1),   # the proj_out-composed feed-forward GEMM -> a motion module's norm
     ("gemm", 2, 5, 16, 16, 640, 640, True, 2, 5),
+    ("conv+1x1", 2, 5, 32, 32, 128, 640, False, 2, -1),   # conv2 + conv_shortcut (rcdm_conv3x3_add1x1_gnstat) -> a transformer's norm
+    ("conv+1x1", 2, 5, 16, 16, 128, 320, True, 4, 9),     # ... on 160x160 tiles (cross-frame norm): the second input's k-steps in the last slab
 ])
 def test_splitk_gnstat_is_bit_identical(hiplib, kind, b, f, H, W, cin, cout, cross, split, variant):
     """rcdm_conv3x3_gnstat / rcdm_gemm_gnstat + rcdm_groupnorm_silu_prestat (the split-K reduce pass leaves the partial
@@ -591,7 +593,19 @@ def test_splitk_gnstat_is_bit_identical(hiplib, kind, b, f, H, W, cin, cout, cro
     ldc = cout + 8
     gnd = hip.GroupNormDesc(samples, rps, cout, 32, ldc, cout, 1e-5 if cross else 1e-6, int(cross))
     epi = 1 | 2 | 4
-    if kind == "conv":
+    if kind == "conv+1x1":
+        cin2 = 192
+        x = h16(torch.randn(M, cin, generator=g)).half().to(DEV)
+        x2 = h16(torch.randn(M, cin2, generator=g)).half().to(DEV)
+        w = h16(torch.randn(cout, 9 * cin + cin2, generator=g) * (9 * cin) ** -0.5).half().to(DEV)
+        d = hip.ConvDesc(n_img, H, W, cin, cout, 1, 0, cin, ldc, cout, epi, f * H * W, cout, 1.0, split, 0, 0, cin2, cin2)
+        wsb = hip.conv3x3_workspace_bytes(d)
+        ok = hip.conv3x3_gnstat_ok(d, gnd)
+        plain = lambda o, k: hip.conv3x3_add1x1(d, x.data_ptr(), x2.data_ptr(), w.data_ptr(), bias.data_ptr(), rv.data_ptr(), res.data_ptr(),
+                                                o.data_ptr(), k.data_ptr(), k.numel())
+        fused = lambda o, k, gk: hip.conv3x3_add1x1_gnstat(d, gnd, x.data_ptr(), x2.data_ptr(), w.data_ptr(), bias.data_ptr(), rv.data_ptr(),
+                                                          res.data_ptr(), o.data_ptr(), k.data_ptr(), k.numel(), gk.data_ptr(), gk.numel())
+    elif kind == "conv":
         x = h16(torch.randn(M, cin, generator=g)).half().to(DEV)
         w = h16(torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(DEV)
         d = hip.ConvDesc(n_img, H, W, cin, cout, 1, 0, cin, ldc, cout, epi, f * H * W, cout, 1.0, split, 0, 0)
