@@ -508,10 +508,11 @@ struct XAttnArgs {
   int batch, heads, Lq, Lk, d;
   int ldq, ldo;
   float c;  // scale * log2(e)
+  int qi;   // chunks of NW * 32 queries a block walks through (same batch and head: one copy of the image serves them all)
 };
 
 template <int DS, int NW>
-__global__ __launch_bounds__(NW * 64) void xattn_kernel(const XAttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 && DS <= 3) ? 4 : 2) void xattn_kernel(const XAttnArgs p) {   // (second bound = waves per SIMD: two blocks of 8 waves per CU — 128 registers — for every head width but the 160-wide one)
   constexpr int DF = (DS + 1) / 2;
   constexpr int NFRAG = 3 * DS + 6 * DF;  // 1-KiB operand fragments of one (batch, head): K then V^T
   extern __shared__ __attribute__((aligned(16))) char xa_smem[];
@@ -519,12 +520,17 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const XAttnArgs p) {
   const int lr = lane & 31, hi = lane >> 5;
   // a block = 8 waves x 32 queries of ONE (batch, head): its fragment image is copied to LDS once and read by all
   // eight (every wave fetching its own copy from L2 — 21 KB per 32 queries at d = 40 — ran at the L2 -> CU delivery limit)
+  // A block walks through p.qi such chunks (round 5): the image copy — 80 bytes per query against the 160 of Q in + O out —
+  // and the launch's latency chain (image, Q, one barrier, 21 MFMAs, 48 exps, store) are paid once per qi chunks, and the Q
+  // rows of chunk i + 1 are requested before chunk i is computed.
   constexpr int BQ = NW * 32;
   const int nqb = (p.Lq + BQ - 1) / BQ;
-  const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
+  constexpr bool PF = DS <= 3;   // the chunk loop (with the next chunk's Q rows prefetched) for the narrow heads only: the wide ones have
+                                 // no registers to spare at 4 waves per SIMD and few query chunks per head anyway (host: qi = 1)
+  const int qi = PF ? p.qi : 1;
+  const int npb = (nqb + qi - 1) / qi;          // blocks per (batch, head)
+  const int bh = blockIdx.x / npb, qb0 = (blockIdx.x - bh * npb) * qi;
   const int b = bh / p.heads, h = bh - b * p.heads;
-  const int q = qb * BQ + wave * 32 + lr;
-  const bool q_ok = q < p.Lq;
   const bool ones_row = p.d < 32 * DF;
   constexpr f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   {
@@ -533,19 +539,31 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const XAttnArgs p) {
     for (int it = threadIdx.x; it < NFRAG * 64; it += NW * 64)
       ((uint4*)xa_smem)[it] = it < 3 * DS * 64 ? srck[it] : srcv[it - 3 * DS * 64];
   }
-  f16x8 qf[DS];
-  const f16* qrow = p.Q + ((size_t)b * p.Lq + (q_ok ? q : 0)) * p.ldq + h * p.d;
+  f16x8 qf[DS], qn[PF ? DS : 1];
+  auto load_q = [&](int qb, f16x8 (&dst)[DS]) __attribute__((always_inline)) {
+    const int q = qb * BQ + wave * 32 + lr;
+    const bool ok = q < p.Lq;
+    const f16* qrow = p.Q + ((size_t)b * p.Lq + (ok ? q : 0)) * p.ldq + h * p.d;
 #pragma unroll
-  for (int s = 0; s < DS; ++s) {
-    const int dc = s * 16 + hi * 8;
-    Pack16 v;
-    v.u = make_uint4(0, 0, 0, 0);
-    if (q_ok && dc < p.d) v.u = *(const uint4*)(qrow + dc);
-    qf[s] = v.h;
-  }
+    for (int s = 0; s < DS; ++s) {
+      const int dc = s * 16 + hi * 8;
+      Pack16 v;
+      v.u = make_uint4(0, 0, 0, 0);
+      if (ok && dc < p.d) v.u = *(const uint4*)(qrow + dc);
+      dst[s] = v.h;
+    }
+  };
+  load_q(qb0, qf);
   __syncthreads();
-  if (qb * BQ + wave * 32 >= p.Lq) return;  // a wave past the last query (no barrier follows)
   const char* frag = xa_smem + lane * 16;
+  for (int it = 0; it < qi; ++it) {
+  const int qb = qb0 + it;
+  if (qb * BQ + wave * 32 >= p.Lq) return;  // a wave past the last query (no barrier follows)
+  const int q = qb * BQ + wave * 32 + lr;
+  const bool q_ok = q < p.Lq;
+  if constexpr (PF) {
+    if (it + 1 < qi) load_q(qb + 1, qn);    // (rows past Lq are not dereferenced)
+  }
 
   // ---- S^T: three 32-key tiles
   f32x16 sacc[3];
@@ -604,19 +622,25 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const XAttnArgs p) {
     l_tot = lsum + __shfl_xor(lsum, 32, 64);
   }
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (!q_ok) return;
-  f16* ob = p.O + ((size_t)b * p.Lq + q) * p.ldo + h * p.d;
+  if (q_ok) {
+    f16* ob = p.O + ((size_t)b * p.Lq + q) * p.ldo + h * p.d;
 #pragma unroll
-  for (int f = 0; f < DF; ++f)
+    for (int f = 0; f < DF; ++f)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int dd = f * 32 + g * 8 + hi * 4;
-      if (dd < p.d) {
-        f16x4 o = {(f16)(oacc[f][4 * g] * inv), (f16)(oacc[f][4 * g + 1] * inv), (f16)(oacc[f][4 * g + 2] * inv),
-                   (f16)(oacc[f][4 * g + 3] * inv)};
-        *(f16x4*)(ob + dd) = o;
+      for (int g = 0; g < 4; ++g) {
+        const int dd = f * 32 + g * 8 + hi * 4;
+        if (dd < p.d) {
+          f16x4 o = {(f16)(oacc[f][4 * g] * inv), (f16)(oacc[f][4 * g + 1] * inv), (f16)(oacc[f][4 * g + 2] * inv),
+                     (f16)(oacc[f][4 * g + 3] * inv)};
+          *(f16x4*)(ob + dd) = o;
+        }
       }
-    }
+  }
+  if constexpr (PF) {
+#pragma unroll
+    for (int s = 0; s < DS; ++s) qf[s] = qn[s];
+  }
+  }
 }
 
 // K, V [batch*Lk][ld] (head h at columns h*d ..) -> the fragment-major image: thread = one lane slot (16 bytes) of one
@@ -855,7 +879,27 @@ int rcdm_xattn(const rcdm_attn_desc* d, const void* Q, const void* image, void* 
     nw_mode = e ? atoi(e) : 8;
   }
   const int nw = nw_mode == 4 ? 4 : 8;  // measured at the 64x64 level: 4 waves 26.7 us, 8 waves 21.2, 16 waves 23.5
-  const dim3 grid((unsigned)(d->batch * d->heads * ((d->Lq + nw * 32 - 1) / (nw * 32)))), block(nw * 64);
+  // query chunks per block: as many (<= 4) as leave one block per CU (RCDM_XATTN_QI overrides: A/B switch).  Same-box A/B at
+  // the 64x64 level's five launches: 1 / 2 / 4 chunks = 17.685 / 17.645 / 17.638 ms per step
+  static int qi_mode = -1;
+  if (qi_mode < 0) {
+    const char* e = getenv("RCDM_XATTN_QI");
+    qi_mode = e ? atoi(e) : 0;
+  }
+  const int nqb = (d->Lq + nw * 32 - 1) / (nw * 32);
+  int qi = qi_mode > 0 ? qi_mode : 1;
+  if (qi_mode <= 0) {
+    static int cus = 0;
+    if (cus <= 0) {
+      int dev = 0, n = 0;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    while (qi < 4 && d->batch * d->heads * ((nqb + 2 * qi - 1) / (2 * qi)) >= cus) qi *= 2;
+  }
+  if (qi > nqb) qi = nqb;
+  if (DS > 3) qi = 1;   // (the wide-head instantiations have no chunk loop)
+  a.qi = qi;
+  const dim3 grid((unsigned)(d->batch * d->heads * ((nqb + qi - 1) / qi))), block(nw * 64);
   const size_t lds = (size_t)(3 * DS + 6 * DF_) * 1024;
   hipStream_t stream = (hipStream_t)stream_;
 #define XA_LAUNCH(DS_)                                                                \
