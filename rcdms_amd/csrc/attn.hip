@@ -702,18 +702,35 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs p) {
   // ---- stage: a wave takes whole rows (pl, f), its lanes the row's 16-B chunks: the row -> address arithmetic
   // (divisions by runtime values) happens once per row on wave-uniform values, not once per chunk
   const int lane = t & 63, wave = t >> 6;
+  // Four rows per wave and pass, all their loads issued before the first LDS write (round 5): with one row at a time a wave
+  // had one or two 16-byte loads in flight and the kernel lived on occupancy alone.
   const int nrows = p.tpb * F;
-  for (int r = wave; r < nrows; r += 4) {
-    const int f = r % F, pl = r / F;
-    const int px = (int)px0 + pl;
-    const bool ok = px < (int)total_px;
-    const int b = ok ? px / p.pixels : 0, pix = px - b * p.pixels;
-    const f16* src = p.qkv + ((long)(b * F + f) * p.pixels + pix) * (long)p.ldqkv;
-    f16* dst = tile + (size_t)r * C3;
+  constexpr int SU = 4;
+  for (int r0 = wave; r0 < nrows; r0 += 4 * SU) {
+    const f16* src[SU];
+    f16* dst[SU];
+    bool ok[SU], live[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int r = r0 + 4 * u;
+      live[u] = r < nrows;
+      const int f = r % F, pl = r / F;
+      const int px = (int)px0 + pl;
+      ok[u] = live[u] && px < (int)total_px;
+      const int b = ok[u] ? px / p.pixels : 0, pix = px - b * p.pixels;
+      src[u] = p.qkv + ((long)(b * F + f) * p.pixels + (ok[u] ? pix : 0)) * (long)p.ldqkv;
+      dst[u] = tile + (size_t)(live[u] ? r : 0) * C3;
+    }
     for (int c = lane; c < rowc; c += 64) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *(const uint4*)(src + c * 8);
-      *(uint4*)(dst + c * 8) = v;
+      uint4 v[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (ok[u]) v[u] = *(const uint4*)(src[u] + c * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u)
+        if (live[u]) *(uint4*)(dst[u] + c * 8) = v[u];
     }
   }
   __syncthreads();
