@@ -536,8 +536,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && DS <= 3) ? 4 : 2) void xattn_k
   {
     const uint4* srck = (const uint4*)(p.KF + (size_t)bh * 3 * DS * 512);
     const uint4* srcv = (const uint4*)(p.VF + (size_t)bh * 6 * DF * 512);
-    for (int it = threadIdx.x; it < NFRAG * 64; it += NW * 64)
-      ((uint4*)xa_smem)[it] = it < 3 * DS * 64 ? srck[it] : srcv[it - 3 * DS * 64];
+    // (all of a thread's chunks requested before the first LDS write: one memory round trip for the image, not one per pass)
+    constexpr int NIT = (NFRAG * 64 + NW * 64 - 1) / (NW * 64);
+    uint4 tmp[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = threadIdx.x + k * NW * 64;
+      tmp[k] = make_uint4(0, 0, 0, 0);
+      if (it < NFRAG * 64) tmp[k] = *(it < 3 * DS * 64 ? srck + it : srcv + (it - 3 * DS * 64));
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = threadIdx.x + k * NW * 64;
+      if (it < NFRAG * 64) ((uint4*)xa_smem)[it] = tmp[k];
+    }
   }
   f16x8 qf[DS], qn[PF ? DS : 1];
   auto load_q = [&](int qb, f16x8 (&dst)[DS]) __attribute__((always_inline)) {
