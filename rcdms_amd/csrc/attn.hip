@@ -905,11 +905,15 @@ int rcdm_xattn(const rcdm_attn_desc* d, const void* Q, const void* image, void* 
   static int nw_mode = -1;  // RCDM_XATTN_WAVES=4|8: waves (x 32 queries) per block (A/B switch)
   if (nw_mode < 0) {
     const char* e = getenv("RCDM_XATTN_WAVES");
-    nw_mode = e ? atoi(e) : 8;
+    nw_mode = e ? atoi(e) : 4;
   }
-  const int nw = nw_mode == 4 ? 4 : 8;  // measured at the 64x64 level: 4 waves 26.7 us, 8 waves 21.2, 16 waves 23.5
-  // query chunks per block: as many (<= 4) as leave one block per CU (RCDM_XATTN_QI overrides: A/B switch).  Same-box A/B at
-  // the 64x64 level's five launches: 1 / 2 / 4 chunks = 17.685 / 17.645 / 17.638 ms per step
+  // Back to back (round 2) 8 waves won at the 64x64 level (21.2 us against 26.7 for 4, 23.5 for 16); in the replayed step
+  // graph 4 waves are -0.07 ms per step over the sixteen launches (round 5, five same-box pairs: twice the blocks for the
+  // 16x16 / 8x8 levels' 80 heads, and a cold image reaches 4 waves sooner than 8)
+  const int nw = nw_mode == 8 ? 8 : 4;
+  // query chunks per block: as many (<= 4 with 8 waves, <= 2 with 4) as leave one block per CU (RCDM_XATTN_QI overrides: A/B
+  // switch).  Same-box A/B at the 64x64 level's five launches, 8 waves: 1 / 2 / 4 chunks = 17.685 / 17.645 / 17.638 ms per step;
+  // with 4 waves the chunk count is within the noise (1 / 2 / 4: 17.28 / 17.27 / 17.28)
   static int qi_mode = -1;
   if (qi_mode < 0) {
     const char* e = getenv("RCDM_XATTN_QI");
@@ -923,7 +927,8 @@ int rcdm_xattn(const rcdm_attn_desc* d, const void* Q, const void* image, void* 
       int dev = 0, n = 0;
       cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     }
-    while (qi < 4 && d->batch * d->heads * ((nqb + 2 * qi - 1) / (2 * qi)) >= cus) qi *= 2;
+    const int cap = nw == 8 ? 4 : 2;
+    while (qi < cap && d->batch * d->heads * ((nqb + 2 * qi - 1) / (2 * qi)) >= cus) qi *= 2;
   }
   if (qi > nqb) qi = nqb;
   if (DS > 3) qi = 1;   // (the wide-head instantiations have no chunk loop)
