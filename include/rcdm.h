@@ -25,7 +25,12 @@
 extern "C" {
 #endif
 
-#define RCDM_VERSION 0x000100 /* 0.1.0 */
+#define RCDM_VERSION 0x000200 /* 0.2.0 */
+/* ABI rule: every descriptor struct below MUST be zero-initialised by the caller (memset / `= {0}` / calloc) before its
+ * fields are set.  Descriptors grow at the END between versions and a zero in a field this header does not describe yet
+ * always means "the behaviour of the previous version": 0.2.0 added rcdm_conv3x3_desc.c_in2 / lda2 (rcdm_conv3x3_add1x1)
+ * and rcdm_attn_desc.flags (RCDM_ATTN_WIDE_RANGE) — a caller compiled against 0.1.0 that did not zero its structs passes
+ * garbage there; rcdm_conv3x3 returns RCDM_EINVAL for c_in2 != 0 in every form, the phase form (upsample = 2) included. */
 
 /* error codes */
 #define RCDM_OK 0
@@ -115,6 +120,9 @@ typedef struct {
   int32_t C;                  /* LayerNorm width = K of the consumer */
 } rcdm_lnx;
 int rcdm_gemm_stat_parts(const rcdm_gemm_desc* d);   /* 0: a statistics-producing launch of this shape is not available */
+/* The same for a call that is PRODUCER and, with consumer != 0, also CONSUMER: the consumer flag steers the tile choice too,
+ * so a call that carries both sides must size stat_out from this query (consumer = 0 is rcdm_gemm_stat_parts). */
+int rcdm_gemm_lnx_stat_parts(const rcdm_gemm_desc* d, int32_t consumer);
 /* Workspace an rcdm_gemm_lnx call of this shape needs, with the SAME tile / split decision the call itself takes (statistics
  * producers and consumers are steered to other tile shapes than a plain rcdm_gemm of the shape: rcdm_gemm_workspace_bytes can
  * disagree).  Non-zero means the shape would run split-K, which rcdm_gemm_lnx refuses on either side (RCDM_ESHAPE). */

@@ -1516,6 +1516,16 @@ int rcdm_gemm_stat_parts(const rcdm_gemm_desc* d) {
   return a.splits > 1 ? 0 : a.tilesN;
 }
 
+int rcdm_gemm_lnx_stat_parts(const rcdm_gemm_desc* d, int32_t consumer) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  IgemmArgs a{};
+  from_gemm(d, a);
+  a.stat_out = (float*)16;                       // producer flag, as in rcdm_gemm_stat_parts ...
+  if (consumer) a.lnx_stat = (const float*)16;   // ... and the consumer flag the launch will carry: both steer the tile choice
+  fill_common(a, d->split_k);
+  return a.splits > 1 ? 0 : a.tilesN;
+}
+
 int rcdm_gemm_lnx(const rcdm_gemm_desc* d, const rcdm_lnx* x, const void* A, const void* W, const float* bias,
                   const float* rowvec, const void* residual, void* out, void* workspace, size_t workspace_bytes,
                   void* stream) {
@@ -1576,7 +1586,10 @@ int rcdm_gemm_ln(const rcdm_gemm_desc* d, const rcdm_ln_fuse* ln, const void* A,
 size_t rcdm_conv3x3_workspace_bytes(const rcdm_conv3x3_desc* d) {
   if (!d) return 0;
   IgemmArgs a{};
-  if (d->upsample == 2) return plan_up2(d, a) >= 0 && a.splits > 1 ? (size_t)a.splits * a.M * a.N * sizeof(float) : 0;
+  if (d->upsample == 2) {
+    if (d->c_in2) return 0;   // (no phase form with a second input: every launch entry refuses the pair)
+    return plan_up2(d, a) >= 0 && a.splits > 1 ? (size_t)a.splits * a.M * a.N * sizeof(float) : 0;
+  }
   if (from_conv(d, a) || a.Cin <= 0 || a.N <= 0) return 0;
   fill_common(a, d->split_k);
   return a.splits > 1 ? (size_t)a.splits * a.M * a.N * sizeof(float) : 0;
@@ -1585,6 +1598,7 @@ size_t rcdm_conv3x3_workspace_bytes(const rcdm_conv3x3_desc* d) {
 int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, const float* bias, const float* rowvec,
                  const void* residual, void* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!d) return RCDM_EINVAL;
+  if (d->c_in2) return RCDM_EINVAL;   // (a descriptor of rcdm_conv3x3_add1x1 — refused in every form, the phase form included)
   IgemmArgs a{};
   if (d->upsample == 2) {
     const int shape = plan_up2(d, a);
@@ -1606,7 +1620,6 @@ int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, cons
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return rcdm_check_launch();
   }
-  if (d->c_in2) return RCDM_EINVAL;   // (a descriptor of rcdm_conv3x3_add1x1)
   return conv_launch(d, nullptr, in, nullptr, W, bias, rowvec, residual, out, workspace, workspace_bytes, nullptr, 0, stream);
 }
 

@@ -89,6 +89,7 @@ SYMBOLS = {
     "rcdm_last_hip_error_string": (C.c_char_p, []),
     "rcdm_gemm_ln": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(LnFuse), _P, _P, _P, _P, _P, _P]),
     "rcdm_gemm_stat_parts": (C.c_int, [C.POINTER(GemmDesc)]),
+    "rcdm_gemm_lnx_stat_parts": (C.c_int, [C.POINTER(GemmDesc), _I]),
     "rcdm_gemm_lnx_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc), _I, _I]),
     "rcdm_set_groupnorm_fold": (C.c_int, [_I]),
     "rcdm_gemm_lnx": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(Lnx), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -311,7 +312,11 @@ def set_groupnorm_fold(on):
     _check(load().rcdm_set_groupnorm_fold(int(on)), "rcdm_set_groupnorm_fold")
 
 
-def gemm_stat_parts(desc):
+def gemm_stat_parts(desc, consumer=False):
+    """Column-tile count (= statistics slots per row) of a statistics-producing launch of this shape; consumer: the launch
+    also consumes a deferred LayerNorm (both flags steer the tile choice: rcdm_gemm_lnx_stat_parts)."""
+    if consumer:
+        return int(load().rcdm_gemm_lnx_stat_parts(C.byref(desc), 1))
     return int(load().rcdm_gemm_stat_parts(C.byref(desc)))
 
 

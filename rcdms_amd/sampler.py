@@ -42,11 +42,20 @@ class DenoiseLoop:
         # the update in rcdm_cfg_pndm_step from the scheduler's own per-call table
         self.pndm = hasattr(scheduler, "plms_table")
         self.T = len(ts)
+        self._pndm_next = 0   # PNDM only: the schedule row the PLMS history in self.hist is valid for (run() checks it)
         if self.pndm:
             self.coef = scheduler.plms_table().to(dev)
             self.hist = torch.zeros(5, stories * 4 * frames * height * width, dtype=torch.float32, device=dev)
         else:
+            # the fused step is DDIM: the timestep list must be DDIM's — strictly decreasing at the constant stride
+            # num_train_timesteps // T.  A multistep scheduler without plms_table() (e.g. a diffusers PNDMScheduler object:
+            # alphas_cumprod, but N + 1 timesteps with the second one repeated) must not be run with DDIM coefficients.
             ratio = int(cfg.get("num_train_timesteps", 1000)) // self.T
+            tl = ts.tolist()
+            if getattr(cfg, "skip_prk_steps", None) is not None or any(a - b != ratio for a, b in zip(tl, tl[1:])):
+                raise NotImplementedError(
+                    f"{type(scheduler).__name__}: its timesteps are not a DDIM schedule of stride {ratio} (a multistep "
+                    "scheduler?) — pass rcdms_amd.scheduler.DDIMScheduler or rcdms_amd.scheduler.PNDMScheduler")
             ac = torch.as_tensor(scheduler.alphas_cumprod).double().cpu()
             final = torch.as_tensor(getattr(scheduler, "final_alpha_cumprod", 1.0)).double().cpu()
             rows = []
@@ -168,6 +177,7 @@ class DenoiseLoop:
             ctx = ctx[self.split.half * n:(self.split.half + 1) * n]
         self.prog.set_context(ctx, force=True)   # ~3 MB + 16 small GEMMs per story: never trust a cache here
         self.step_dev.zero_()
+        self._pndm_next = 0
         torch.cuda.current_stream(self.device).synchronize()
 
     def run(self, callback=None, callback_steps=1, use_graph=True, start=0, steps=None):
@@ -178,15 +188,23 @@ class DenoiseLoop:
         stop = self.T if steps is None else start + int(steps)
         if not (0 <= start < stop <= self.T):
             raise ValueError(f"steps [{start}, {stop}) outside the {self.T}-step schedule")
+        if self.pndm and start not in (0, self._pndm_next):
+            # the PLMS step is stateful (four prediction slots + the saved first sample in self.hist): a run can only
+            # continue where the previous one stopped, or start over
+            raise ValueError(f"PNDM: run(start={start}) but the multistep history is valid for step {self._pndm_next} "
+                             "(continue there, or start at 0 after load())")
         cur = torch.cuda.current_stream(self.device)
         p.stream.wait_stream(cur)
         with torch.cuda.stream(p.stream):
             if use_graph and self.graph is None:
                 # warm every kernel up once outside capture (lazy function loading), then restore the state
                 lat0 = self.lat.clone()
+                hist0 = self.hist.clone() if self.pndm else None   # (table row 0 overwrites slot 0 and the saved sample)
                 self.step_dev.zero_()   # the warm-up step reads table / coefficient row `step`: keep it inside the tables
                 self._one_step_eager()
                 self.lat.copy_(lat0)
+                if hist0 is not None:
+                    self.hist.copy_(hist0)
                 self.step_dev.zero_()
                 p.stream.synchronize()
                 self.graph = p.capture(pre=self._pre, post=self._post, skip_time=True)
@@ -199,6 +217,7 @@ class DenoiseLoop:
                 if callback is not None and i % callback_steps == 0:
                     p.stream.synchronize()
                     callback(i, int(self.timesteps[i]), self.lat)
+        self._pndm_next = stop
         cur.wait_stream(p.stream)
         return self.lat
 
