@@ -65,15 +65,19 @@ def init_weights_(model, seed=0):
                 p.normal_(0, fan_in ** -0.5, generator=g)
 
 
-def build_model(device):
+def build_model(device, width=0):
+    """The stage-2 UNet (SD-1.5 widths 320 / 640 / 1280 / 1280, 1276.9 M parameters); width > 0: the same topology at that
+    base width with a width-wide context (harness tests only)."""
     from src.models.unet import UNet3DConditionModel
     mk = dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
               temporal_position_encoding=True, temporal_position_encoding_max_len=5, temporal_attention_dim_div=1)
+    extra = dict(block_out_channels=(width, 2 * width, 4 * width, 4 * width), cross_attention_dim=width) if width else \
+        dict(cross_attention_dim=768)
     with torch.device("meta"):
-        m = UNet3DConditionModel(sample_size=64, in_channels=9, cross_attention_dim=768, use_motion_module=True,
+        m = UNet3DConditionModel(sample_size=64, in_channels=9, use_motion_module=True,
                                  motion_module_resolutions=[1, 2, 4, 8], unet_use_cross_frame_attention=False,
                                  unet_use_temporal_attention=False, motion_module_type="Vanilla",
-                                 motion_module_kwargs=mk)
+                                 motion_module_kwargs=mk, **extra)
     m = m.to_empty(device=device).eval()
     init_weights_(m)
     return m
@@ -106,8 +110,132 @@ def cpu_baseline(model, latent, ctx_len, ddim_steps, budget_s=200.0):
     how = (f"1 warm-up ({warm:.1f} s) + {n} timed UNet calls of the {ddim_steps} per story at {latent}x{latent} latents: "
            f"median {t_call:.1f} s, min {ts[0]:.1f}, max {ts[-1]:.1f}")
     fps = 5.0 / (ddim_steps * t_call)
-    return {"value": fps, "unit": "story-frames/s", "cores": threads, "kind": "port",
-            "sample": how + f"; b=2 f=5 L={ctx_len}, fp32 torch CPU restatement, extrapolated x{ddim_steps} steps"}
+    return {"value": fps, "unit": "story-frames/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+            "sample": how + f"; b=2 f=5 L={ctx_len}, fp32 torch CPU restatement on {threads} threads of this box's "
+                            f"{os.cpu_count()} host cores, extrapolated x{ddim_steps} steps"}
+
+
+def ddim():
+    from rcdms_amd.scheduler import DDIMScheduler
+    return DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+
+
+def time_stage2(model, S, latent, L, T, passes, structure="dense", guidance=2.0):
+    """One secondary stage-2 configuration on the SAME model: 1 warm-up pass + `passes` timed passes of the T-step loop
+    (HIP events on the loop's stream around every pass + the wall clock around all of them)."""
+    from rcdms_amd import hip, synth
+    from rcdms_amd.sampler import DenoiseLoop
+    loop = DenoiseLoop(model, S, 5, latent, latent, L, guidance, ddim(), T)
+    st = synth.synthetic_story(stories=S, latent_hw=(latent, latent), ctx_len=L, seed=42, structure=structure)
+
+    def one():
+        loop.load(st["latents"], st["mask"], st["masked_latents"], st["ctx"])
+        loop.run()
+    one()
+    torch.cuda.synchronize()
+    ev0, ev1 = hip.Event(), hip.Event()
+    gpu_ms, t0 = 0.0, time.perf_counter()
+    for _ in range(passes):
+        loop.load(st["latents"], st["mask"], st["masked_latents"], st["ctx"])
+        sp = loop.prog.stream.cuda_stream
+        ev0.record(sp)
+        loop.run()
+        ev1.record(sp)
+        torch.cuda.synchronize()
+        gpu_ms += ev0.elapsed_ms(ev1)
+    dt = time.perf_counter() - t0
+    step_ms = gpu_ms / (passes * T)
+    tf = ALGO_TFLOP_PER_CALL.get(latent)
+    out = {"workload": f"{'FlintstonesSV' if L == 91 else 'PororoSV'} stage-2, {latent * 8}x{latent * 8}, {T}-step DDIM, CFG {guidance}, "
+                       f"batch={S} story x 5 frames, ctx {L}x768" + (", context rows as the reference's builders produce them "
+                       "(2 dense images + 8 with L identical rows: SURVEY F6)" if structure == "reference" else ""),
+           "passes": passes, "ms_per_step": round(1e3 * dt / passes, 3), "value": round(5 * S * passes / dt, 4),
+           "unit": "story-frames/s", "avg_launch_ms": round(step_ms, 4),
+           "frac": round(tf * S / (step_ms * 1e-3) / MFMA_F16_PEAK_TFLOPS, 4) if tf else None,
+           "shared_cfg_prefix": bool(loop.shared), "rank1_context_plan": loop.rank1_runs is not None,
+           "kernels_per_step": loop.prog.plan.n_launch}
+    del loop
+    return out
+
+
+def time_prior(passes, sample_steps=50, guidance=4.0):
+    """BASELINE config 5 (stage-1 frame-prior transformer, 50-step UnCLIP, 5 frames with CFG) — tools/bench_prior.py's
+    measurement, 1 warm-up + `passes` timed stories."""
+    import re
+    from rcdms_amd import hip
+    from rcdms_amd.sampler import PriorLoop
+    from rcdms_amd.scheduler import UnCLIPScheduler
+    from src.models.myprior_transformer import MyPriorTransformer
+    dev = torch.device("cuda", torch.cuda.current_device())
+    mk = dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
+              temporal_position_encoding=True, temporal_position_encoding_max_len=5, temporal_attention_dim_div=1)
+    with torch.device("meta"):
+        m = MyPriorTransformer(num_attention_heads=32, attention_head_dim=64, num_layers=20, embedding_dim=1280,
+                               num_embeddings=91, additional_embeddings=6, unet_use_cross_frame_attention=False,
+                               unet_use_temporal_attention=False, use_motion_module=True, motion_module_type="Vanilla",
+                               motion_module_kwargs=mk)
+    m = m.to_empty(device=dev).eval()
+    init_weights_(m)
+    nparam = sum(p.numel() for p in m.parameters())
+    B, T, E = 10, 91, 1280
+    g = torch.Generator(device=dev).manual_seed(42)
+    rn = lambda *shape: torch.randn(*shape, device=dev, generator=g)
+    mask = torch.ones(B, T, device=dev)
+    mask[:, 20:] = 0
+    loop = PriorLoop(m, 5, T, guidance, UnCLIPScheduler(), sample_steps)
+    args = (rn(B, E), rn(B, T, E), rn(B, E), rn(B, E), mask)
+    lat = rn(5, E)
+    loop.load(lat, *args, generator=g)
+    loop.run()
+    torch.cuda.synchronize()
+    ev0, ev1 = hip.Event(), hip.Event()
+    gpu_ms, t0 = 0.0, time.perf_counter()
+    for _ in range(passes):
+        loop.load(lat, *args, generator=g)
+        sp = loop.stream.cuda_stream
+        ev0.record(sp)
+        loop.run()
+        ev1.record(sp)
+        torch.cuda.synchronize()
+        gpu_ms += ev0.elapsed_ms(ev1)
+    dt = time.perf_counter() - t0
+    step_ms = gpu_ms / (passes * sample_steps)
+    flops = 0.0
+    for tag in loop.prog.plan.tags:      # algorithmic work of one step, from the launch plan's own descriptors
+        g_ = re.match(r"gemm M=(\d+) N=(\d+) K=(\d+)", tag)
+        f_ = re.match(r"flash_attn_masked B=(\d+) H=(\d+) L=(\d+) d=(\d+)", tag)
+        if g_:
+            flops += 2.0 * int(g_.group(1)) * int(g_.group(2)) * int(g_.group(3))
+        elif f_:
+            bb, hh, ll, dd = (int(v) for v in f_.groups())
+            flops += 4.0 * bb * hh * ll * ll * dd
+    out = {"workload": f"stage-1 prior transformer, 20 layers x (block + motion module), {nparam / 1e9:.2f} G parameters, batch 10 x 97 "
+                       f"tokens, {sample_steps}-step UnCLIP, CFG {guidance}, f16",
+           "passes": passes, "ms_per_step": round(1e3 * dt / passes, 3), "value": round(passes / dt, 4), "unit": "stories/s",
+           "avg_launch_ms": round(step_ms, 4), "tflop_per_step": round(flops / 1e12, 3),
+           "frac": round(flops / (step_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
+    del loop, m
+    return out
+
+
+def extra_configs(model, passes=3):
+    """The other BASELINE.json configurations the headline does not carry, timed on the SAME box right after the headline loop
+    (so that a driver's run witnesses them): `value` / `ms_per_step` over `passes` full loops each, `frac` = algorithmic
+    TFLOP per UNet call / HIP-event step time / 2500.  Never the headline: SURVEY section 8(d) fixes that as config 2 with a
+    dense N(0,1) context."""
+    out = {}
+    # BASELINE configs[0] shape on the GPU: 256x256, 20-step DDIM, one story (the reference's CPU-runnable case)
+    out["config1_256x256_20step"] = time_stage2(model, 1, 32, 85, 20, passes)
+    # BASELINE configs[2]: FlintstonesSV, 4 stories per batch (b = 8), L = 91
+    out["config3_flintstones_batch4"] = time_stage2(model, 4, 64, 91, 50, passes)
+    # configs[1] again with the context-row structure the reference's own builders produce (rank-1-context plan, SURVEY F6)
+    out["config2_reference_context_rows"] = time_stage2(model, 1, 64, 85, 50, passes, structure="reference")
+    model._invalidate()           # (drop the secondary plans' packed weights and buffers before the prior is built)
+    torch.cuda.empty_cache()
+    # BASELINE configs[4]: stage-1 frame-prior transformer, 50-step sampling
+    out["config5_stage1_prior"] = time_prior(passes)
+    torch.cuda.empty_cache()
+    return out
 
 
 @contextlib.contextmanager
@@ -136,6 +264,12 @@ def parse_args(argv=None):
     ap.add_argument("--ctx-len", type=int, default=85)
     ap.add_argument("--guidance", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the secondary BASELINE configurations (256x256 / 20 steps, FlintstonesSV batch 4, the stage-1 prior, "
+                         "the reference's context-row structure) that a default 1-GPU run times after the headline loop")
+    ap.add_argument("--context", choices=("dense", "reference"), default="dense",
+                    help="context rows of the synthetic story: dense N(0,1) (the headline, SURVEY 8d) or the structure the "
+                         "reference's context builders produce (2 dense images + 8 with identical rows, SURVEY F6; not the headline)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-share-prefix", action="store_true",
                     help="evaluate the part of the UNet ahead of the first cross-attention for BOTH CFG halves (A/B switch; "
@@ -148,6 +282,15 @@ def parse_args(argv=None):
                     help="TEST ONLY: every rank runs on device 0 and the process group is gloo — the N > 1 code path of this "
                          "file (per-rank build, weight broadcast, sharded stories, barrier / max-over-ranks timing) on a box "
                          "with ONE GPU; the printed line is marked and is not a measurement")
+    ap.add_argument("--watchdog", type=float, default=900.0,
+                    help="N > 1: seconds any phase with a collective in it (build barrier, weight broadcast, warm-up, timed region, "
+                         "gather) may take before this rank reports and exits 86 (rcdms_amd.dist.Watchdog); 0 disables")
+    ap.add_argument("--ragged", action="store_true",
+                    help="TEST ONLY (with --gpus N > 1): odd ranks hand NO finished story to the final gather, so its uneven-shard "
+                         "padding path runs on real device tensors")
+    ap.add_argument("--width", type=int, default=0,
+                    help="TEST ONLY: a UNet of this base width (block_out_channels = w, 2w, 4w, 4w; cross-attention dim w) instead "
+                         "of the 1276.9 M-parameter one, so that N ranks' plans fit ONE device under --share-gpu; the line is INVALID")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="TEST ONLY: exercise the launch / barrier / max-over-ranks harness on CPU (gloo) with a sleep "
                          "in place of the denoising loop; the printed line is marked data=stub and is not a measurement")
@@ -270,22 +413,44 @@ def main(argv=None):
             dist.barrier()      # brings the RCCL communicator up here, banner and all
 
     import __graft_entry__
-    if local_rank == 0:
+    from rcdms_amd import build as rbuild
+    from rcdms_amd.dist import Watchdog
+    # the in-tree library is built (or found up to date: content stamp) ONCE per node by the node's first rank; every other
+    # rank waits, then checks that what it is about to load belongs to these sources — also the whole story on a node without
+    # hipcc, where the shipped rcdms_amd/lib/ must carry the right stamp (rcdms_amd.build.verify)
+    node_first = int(os.environ.get("LOCAL_RANK", "0")) == 0
+    if node_first:
         __graft_entry__.build()
     if dist_on:
-        dist.barrier()      # the in-tree library is built once per node, then loaded by every rank
+        with Watchdog(a.watchdog, f"rank {rank}: build barrier"):
+            dist.barrier()
+    if not node_first:
+        rbuild.verify()
     from rcdms_amd import hip, synth
     from rcdms_amd.sampler import DenoiseLoop
     from rcdms_amd.scheduler import DDIMScheduler
 
-    model = build_model(dev)
+    model = build_model(dev, a.width)
     if dist_on:
         from rcdms_amd.dist import broadcast_module
         # RCCL over xGMI: every replica holds rank 0's weights; matrices travel as f16 (what the kernels consume): 2.55 GB
-        broadcast_module(model, src=0, wire_dtype=torch.float16)
+        with Watchdog(a.watchdog, f"rank {rank}: weight broadcast"):
+            broadcast_module(model, src=0, wire_dtype=torch.float16)
+            torch.cuda.synchronize()
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
     S, T = a.stories, a.ddim_steps
-    story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42 + rank)
+    cdim = a.width or 768
+    story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, ctx_dim=cdim, seed=42 + rank,
+                                  structure=a.context)
+    if dist_on and a.guidance > 1:
+        # the context every rank shares — the unconditional (empty-prompt) rows of the CFG batch are the same text for every
+        # story — is built once on rank 0 and broadcast over RCCL / xGMI (north_star: "RCCL broadcast of the shared
+        # reference/text context"); each rank keeps its own conditional rows.  Outside the timed region.
+        from rcdms_amd.dist import broadcast_context
+        n_u = S * 5
+        shared = story["ctx"][:n_u].to(torch.device("cpu") if a.share_gpu else dev).contiguous()
+        broadcast_context(shared, src=0)
+        story["ctx"] = torch.cat([shared.cpu(), story["ctx"][n_u:]])
     split, units = None, world          # units = independent story batches in flight across the job
     if a.cfg_split:
         from rcdms_amd.dist import CfgSplit
@@ -296,7 +461,8 @@ def main(argv=None):
         else:
             with stdout_to_stderr():
                 split, units = CfgSplit.from_world(), world // 2
-            story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, seed=42 + rank // 2)
+            story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, ctx_dim=cdim,
+                                          seed=42 + rank // 2, structure=a.context)
     loop = DenoiseLoop(model, S, 5, a.latent, a.latent, a.ctx_len, a.guidance, sched, T,
                        share_cfg_prefix=not a.no_share_prefix, cfg_split=split)
 
@@ -304,9 +470,10 @@ def main(argv=None):
         loop.load(story["latents"], story["mask"], story["masked_latents"], story["ctx"])
         loop.run(use_graph=not a.no_graph)
 
-    for _ in range(a.warmup):
-        one_pass()
-    torch.cuda.synchronize()
+    with Watchdog(a.watchdog if dist_on else 0, f"rank {rank}: warm-up passes"):
+        for _ in range(a.warmup):
+            one_pass()
+        torch.cuda.synchronize()
 
     # timed region: inputs are re-staged (a few MB H2D) inside load(); the loop itself is K x T graph replays
     ev0, ev1 = hip.Event(), hip.Event()
@@ -320,14 +487,16 @@ def main(argv=None):
         ev1.record(sp)
         gpu_ms[0] += ev0.elapsed_ms(ev1)
 
-    dt, per_rank = timed_passes(timed_pass, a.steps, dist if dist_on else None, torch.cuda.synchronize,
-                                torch.device("cpu") if a.share_gpu else dev)   # (gloo gathers host tensors)
+    with Watchdog(a.watchdog if dist_on else 0, f"rank {rank}: timed region ({a.steps} passes)"):
+        dt, per_rank = timed_passes(timed_pass, a.steps, dist if dist_on else None, torch.cuda.synchronize,
+                                    torch.device("cpu") if a.share_gpu else dev)   # (gloo gathers host tensors)
 
+    loop_rank1 = loop.rank1_runs is not None
     frames = 5 * S * a.steps * units
     value = frames / dt
     launches = a.steps * T
     avg_launch_ms = gpu_ms[0] / launches
-    tf_call = ALGO_TFLOP_PER_CALL.get(a.latent)
+    tf_call = ALGO_TFLOP_PER_CALL.get(a.latent) if not a.width else None
     traffic, traffic_src = traffic_record(S, a.latent, a.guidance) if not a.cfg_split else (None, None)
     roof = None
     if tf_call is not None:
@@ -372,10 +541,29 @@ def main(argv=None):
             out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             out["rccl_version"] = None
+    if dist_on and not a.cfg_split:
+        # finished latents back to rank 0 (the reference's processes write their own PNGs, stage2_batchtest_rcdms_model.py:
+        # 378-401; a served job collects them): shard sizes are exchanged and padded, so ragged shards work (--ragged: TEST)
+        from rcdms_amd.dist import gather_stories
+        mine = loop.lat.detach().clone()
+        if a.ragged and rank % 2:
+            mine = mine[:0]                      # odd ranks contribute no story: the padding path runs on device tensors
+        with Watchdog(a.watchdog, f"rank {rank}: gather of the finished stories"):
+            got = gather_stories(mine.cpu() if a.share_gpu else mine, dst=0)
+        if rank == 0:
+            want = sum(0 if (a.ragged and r % 2) else S for r in range(world))
+            assert got is not None and got.shape[0] == want and bool(torch.isfinite(got).all()), (None if got is None else got.shape, want)
+            out["gathered_stories"] = int(got.shape[0])
+    if rank == 0 and world == 1 and not a.cfg_split and not a.no_extra_configs and not a.no_graph and a.latent == 64 and S == 1:
+        del loop
+        out["extra_configs"] = extra_configs(model)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, a.latent, a.ctx_len, T)
-    if a.share_gpu:
-        out["data"] = "INVALID (--share-gpu harness test: every rank on ONE device over gloo; not a measurement)"
+    if a.context != "dense":
+        out["config"]["context_rows"] = "reference structure (2 dense images + 8 with identical rows, SURVEY F6): NOT the headline workload"
+        out["config"]["rank1_context_plan"] = loop_rank1
+    if a.share_gpu or a.width or a.ragged:
+        out["data"] = "INVALID (--share-gpu / --width / --ragged harness test: not a measurement)"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -123,6 +123,11 @@ int rcdm_gemm_stat_parts(const rcdm_gemm_desc* d);   /* 0: a statistics-producin
 /* The same for a call that is PRODUCER and, with consumer != 0, also CONSUMER: the consumer flag steers the tile choice too,
  * so a call that carries both sides must size stat_out from this query (consumer = 0 is rcdm_gemm_stat_parts). */
 int rcdm_gemm_lnx_stat_parts(const rcdm_gemm_desc* d, int32_t consumer);
+/* Two producers that fill ONE statistics buffer (the same projection on all rows and, later, on a row subset whose rows it
+ * rewrites: the rank-1-context plan of the cross-attention) must use the same slot count.  rcdm_gemm_lnx therefore also
+ * accepts a stat_parts other than rcdm_gemm_lnx_stat_parts(d, ..) where an LDS-DMA tile with exactly that column-tile
+ * count exists (ceil(N / 64) or ceil(N / 128)) and takes that tile, unsplit; 1 / 0: */
+int rcdm_gemm_lnx_parts_ok(const rcdm_gemm_desc* d, int32_t parts, int32_t consumer);
 /* Workspace an rcdm_gemm_lnx call of this shape needs, with the SAME tile / split decision the call itself takes (statistics
  * producers and consumers are steered to other tile shapes than a plain rcdm_gemm of the shape: rcdm_gemm_workspace_bytes can
  * disagree).  Non-zero means the shape would run split-K, which rcdm_gemm_lnx refuses on either side (RCDM_ESHAPE). */

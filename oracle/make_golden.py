@@ -6,6 +6,8 @@ with procedural name-seeded weights (rcdms_amd/synth.py).  Run in the build cont
     python -m oracle.make_golden --only loop32|loop64|cfg3     # reference-UNet-driven DDIM trajectories / config-3 story
     python -m oracle.make_golden --only eps32|eps64            # reference eps at stored trajectory points x_k (mid / late steps)
     python -m oracle.make_golden --only skewed                 # full-width UNet with the second ("skewed") weight family, 32x32
+    python -m oracle.make_golden --only rank1ctx               # context rows 2..9 with L identical rows each, tiny + full width
+    python -m oracle.make_golden --only sdlike                 # full-width UNet with the third ("sdlike") weight family, 32x32
 
 What is stored: small inputs and the reference outputs (fp32 .npz), plus a digest of the reference's
 state-dict key/shape list so the mirrored classes are checked to have the identical 1286-key layout.
@@ -151,6 +153,55 @@ def full_unet_skewed():
         print("  reference forward %dx%d (skewed weights): %.1f s; |y| rms %.3f max %.3f"
               % (hw, hw, time.time() - t0, y.pow(2).mean().sqrt(), y.abs().max()))
         save(f"unet_full_{hw}_skewed", t=np.int64(ALT_T), y=y, digest=dig, seed=np.int64(ALT_SEED), story_seed=np.int64(ALT_STORY_SEED))
+
+
+@torch.no_grad()
+def rank1_context():
+    """The reference UNet on a context with the row structure its own context builders produce (SURVEY F5 / F6,
+    RCDMs_pipeline.py:444-450): rows 0..1 dense (the seen frame of each CFG half), rows 2..9 with L identical rows each (the
+    unseen frames: semantic_stack has one key / value token) — synth.synthetic_story(structure="reference").  Full width
+    at 32x32 and 64x64 latents (same weights as unet_full_*) and the width-64 topology at 16x16 (with its inputs)."""
+    m = ref_scaffold.build_reference_unet(width=64, cross_dim=64)
+    dig = load_procedural(m, seed=7)
+    s = synth.synthetic_story(stories=1, latent_hw=(16, 16), ctx_len=13, ctx_dim=64, seed=44, structure="reference")
+    x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1)
+    y = m(x, torch.tensor(741), encoder_hidden_states=s["ctx"], return_dict=False)[0]
+    save("unet_tiny_16_rank1ctx", x=x, ctx=s["ctx"], t=np.int64(741), y=y, digest=dig)
+    t0 = time.time()
+    m = ref_scaffold.build_reference_unet()
+    dig = load_procedural(m, seed=0)
+    print("  full UNet built + procedural weights in %.0f s" % (time.time() - t0))
+    for hw, t in ((32, 951), (64, 981)):
+        s = synth.synthetic_story(stories=1, latent_hw=(hw, hw), ctx_len=85, seed=42, structure="reference")
+        x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1)
+        t0 = time.time()
+        y = m(x, torch.tensor(t), encoder_hidden_states=s["ctx"], return_dict=False)[0]
+        print("  reference forward %dx%d (rank-1 context rows 2..9): %.1f s" % (hw, hw, time.time() - t0))
+        save(f"unet_full_{hw}_rank1ctx", t=np.int64(t), y=y, digest=dig)
+
+
+SD_SEED, SD_STORY_SEED, SD_T = 9, 45, 681
+
+
+@torch.no_grad()
+def full_unet_sdlike():
+    """The full-width reference UNet with the THIRD weight family (synth style "sdlike": 50-100x outlier channels feeding the
+    GroupNorms, 25x attention logits) at 32x32 latents; also stores the largest activation the reference sees on its
+    residual stream (max |conv_norm_out input|) so the report of the f16 path can be read against it."""
+    t0 = time.time()
+    m = ref_scaffold.build_reference_unet()
+    dig = load_procedural(m, seed=SD_SEED, style="sdlike")
+    print("  full UNet built + sdlike weights in %.0f s" % (time.time() - t0))
+    seen = {}
+    m.conv_norm_out.register_forward_hook(lambda mod, inp, out: seen.__setitem__("final", float(inp[0].abs().max())))
+    s = synth.synthetic_story(stories=1, latent_hw=(32, 32), ctx_len=85, seed=SD_STORY_SEED)
+    x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1)
+    t0 = time.time()
+    y = m(x, torch.tensor(SD_T), encoder_hidden_states=s["ctx"], return_dict=False)[0]
+    print("  reference forward 32x32 (sdlike weights): %.1f s; |y| rms %.3f max %.3f; max |residual stream| %.1f"
+          % (time.time() - t0, y.pow(2).mean().sqrt(), y.abs().max(), seen["final"]))
+    save("unet_full_32_sdlike", t=np.int64(SD_T), y=y, digest=dig, seed=np.int64(SD_SEED), story_seed=np.int64(SD_STORY_SEED),
+         max_final=np.float32(seen["final"]))
 
 
 @torch.no_grad()
@@ -328,6 +379,10 @@ if __name__ == "__main__":
         print("prior transformer"); prior(["prior_tiny"] + (["prior_full"] if a.full else []))
     if a.full or a.only == "full":
         print("full UNet"); full_unet()
+    if a.only == "rank1ctx":
+        print("rank-1 context rows"); rank1_context()
+    if a.only == "sdlike":
+        print("full UNet, sdlike weights"); full_unet_sdlike()
     if a.only == "skewed":
         print("full UNet, second weight family"); full_unet_skewed()
     if a.only == "pretrained2d":

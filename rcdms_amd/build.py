@@ -40,7 +40,11 @@ def build(force=False, verbose=True):
             if f.read().strip() == stamp:
                 return LIB
     if not os.path.exists(HIPCC):
-        raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build librcdm_hip.so")
+        # a node without the compiler can still RUN a library that was built elsewhere and shipped with the tree — but only the
+        # one that belongs to these sources: never load a stale binary silently
+        have = "missing" if not os.path.exists(LIB) else "present but built from OTHER sources (stamp mismatch)"
+        raise RuntimeError(f"hipcc not found at {HIPCC} and the prebuilt {LIB} is {have}: build the library where hipcc exists "
+                           f"(python -m rcdms_amd.build) and ship rcdms_amd/lib/ with the tree (expected stamp {stamp[:16]}...)")
     objs = []
     procs = []
     for src in SOURCES:
@@ -62,6 +66,21 @@ def build(force=False, verbose=True):
     subprocess.check_call(cmd)
     with open(stamp_file, "w") as f:
         f.write(stamp)
+    return LIB
+
+
+def verify():
+    """The library every rank is about to load IS the one built from this tree's sources (content stamp over csrc/, rcdm.h and
+    the flags): what the ranks that did not build call after the build barrier, and what a node without hipcc relies on.
+    Raises RuntimeError otherwise; returns the library path."""
+    stamp_file = os.path.join(LIBDIR, "build.stamp")
+    if not os.path.exists(LIB) or not os.path.exists(stamp_file):
+        raise RuntimeError(f"{LIB} (or its build.stamp) is missing on this node: the building rank failed or rcdms_amd/lib/ did not ship")
+    with open(stamp_file) as f:
+        have = f.read().strip()
+    want = _stamp()
+    if have != want:
+        raise RuntimeError(f"{LIB} was built from other sources (stamp {have[:16]}... != {want[:16]}...): rebuild with python -m rcdms_amd.build")
     return LIB
 
 

@@ -1108,8 +1108,8 @@ int plan_splits(int tiles, int slots, int nk, int requested) {
   return s;
 }
 
-int fill_common(IgemmArgs& a, int requested_split, int* variant_out = nullptr) {
-  int variant = pick_variant(a);
+int fill_common(IgemmArgs& a, int requested_split, int* variant_out = nullptr, int forced_variant = -1) {
+  int variant = forced_variant >= 0 ? forced_variant : pick_variant(a);
   // the 256x256 LDS-DMA tile is at the 256-register cap: its statistics / deferred-LayerNorm instantiations spilled (12 /
   // 200 B of scratch) and are not built — such launches take the 128x128 tile, also when variant 2 is forced
   if (variant == 2 && (a.stat_out || a.lnx_stat)) variant = 1;
@@ -1126,7 +1126,7 @@ int fill_common(IgemmArgs& a, int requested_split, int* variant_out = nullptr) {
     a.nk += a.Cin2 / BK;
   }
   int s;
-  const ShapeRule* rule = (g_force_variant == 99 && requested_split <= 0) ? find_shape_rule(a) : nullptr;
+  const ShapeRule* rule = (g_force_variant == 99 && requested_split <= 0 && forced_variant < 0) ? find_shape_rule(a) : nullptr;
   if (rule && rule->split > 0) {
     s = rule->split;
   } else if (is_pp(variant) && requested_split <= 0) {
@@ -1139,6 +1139,16 @@ int fill_common(IgemmArgs& a, int requested_split, int* variant_out = nullptr) {
   a.nk_per_split = (a.nk + s - 1) / s;
   a.splits = (a.nk + a.nk_per_split - 1) / a.nk_per_split;
   return RCDM_OK;
+}
+
+// A statistics producer whose caller asks for another slot count than this shape's own tile choice gives (two producers
+// that fill ONE statistics buffer — e.g. the same projection run on all rows and on a row subset — must agree on it): the
+// LDS-DMA tile whose column-tile count is `parts` (64- or 128-wide tiles), -1 when there is none.
+int variant_for_parts(const IgemmArgs& a, int parts) {
+  const int n64 = (a.N + 63) / 64, n128 = (a.N + 127) / 128;
+  if (parts == n128) return 1;
+  if (parts == n64) return ((a.M + 127) / 128) * n64 < num_cus() ? 4 : 5;
+  return -1;
 }
 
 int check_common(const IgemmArgs& a) {
@@ -1552,7 +1562,23 @@ int rcdm_gemm_lnx(const rcdm_gemm_desc* d, const rcdm_lnx* x, const void* A, con
   }
   int variant = 0;
   fill_common(a, d->split_k, &variant);
+  if (a.stat_out && a.stat_parts != a.tilesN) {   // the caller's slot count, where an LDS-DMA tile has it (rcdm_gemm_lnx_parts_ok)
+    const int alt = variant_for_parts(a, a.stat_parts);
+    if (alt < 0) return RCDM_ESHAPE;
+    fill_common(a, 1, &variant, alt);             // (a statistics launch is never split)
+  }
   return launch<1>(a, variant, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int rcdm_gemm_lnx_parts_ok(const rcdm_gemm_desc* d, int32_t parts, int32_t consumer) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || parts <= 0 || (d->epilogue & RCDM_EPI_GEGLU)) return 0;
+  IgemmArgs a{};
+  from_gemm(d, a);
+  a.stat_out = (float*)16;
+  if (consumer) a.lnx_stat = (const float*)16;
+  fill_common(a, d->split_k);
+  if (a.splits == 1 && a.tilesN == parts) return 1;
+  return variant_for_parts(a, parts) >= 0;
 }
 
 int rcdm_gemm_ln(const rcdm_gemm_desc* d, const rcdm_ln_fuse* ln, const void* A, const void* W, const float* bias,

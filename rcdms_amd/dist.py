@@ -15,6 +15,49 @@ import torch
 import torch.distributed as dist
 
 
+class Watchdog:
+    """Bounded wait around a phase that contains collectives (weight broadcast, a CFG-split loop whose step graph holds an
+    RCCL all-gather, the final gather): a peer that never arrives leaves this process blocked inside a HIP / RCCL call that
+    no Python exception can interrupt, so after `seconds` a timer thread reports what was running — with the library's last
+    RCCL error (rcdm_comm_last_error) — and ends the process with exit code 86; the launcher (torch.distributed.run) then
+    tears the other ranks down.  A hung pair fails loudly inside the caller's own timeout instead of consuming it.
+        with Watchdog(600, "rank 3: timed region"): ...
+    seconds <= 0 disables it."""
+    EXIT_CODE = 86
+
+    def __init__(self, seconds, what, on_expire=None):
+        self.seconds, self.what, self.on_expire, self._t = float(seconds), what, on_expire, None
+
+    def _fire(self):
+        import os
+        import sys
+        err = "n/a"
+        try:
+            from . import hip
+            if hip._lib is not None:
+                err = str(hip._lib.rcdm_comm_last_error())
+        except Exception:
+            pass
+        print(f"[rcdms_amd.dist.Watchdog] '{self.what}' did not finish within {self.seconds:.0f} s — a peer rank is missing or a "
+              f"collective hangs (rcdm_comm_last_error = {err}); aborting this rank", file=sys.stderr, flush=True)
+        if self.on_expire is not None:
+            self.on_expire()
+        os._exit(self.EXIT_CODE)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            import threading
+            self._t = threading.Timer(self.seconds, self._fire)
+            self._t.daemon = True
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._t is not None:
+            self._t.cancel()
+        return False
+
+
 def split_stories(n_stories, world_size):
     """Contiguous near-equal shards, first shards one longer (reference split_list, :58-70)."""
     base, extra = divmod(n_stories, world_size)

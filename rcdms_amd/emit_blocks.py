@@ -10,6 +10,7 @@ from . import switches as SW
 from .emit_ops import (XATTN_MAX_KEYS, assert_no_pending_gn, emit_conv3x3, emit_flash_attn, emit_gemm, emit_groupnorm, emit_groupnorm_stats,
                        emit_layernorm, emit_temporal_attn, emit_xattn, emit_xattn_pack, gemm_lnx_ok)
 from .packer import MSUB_SCORE_LIMIT, attn_score_bound
+from .plan import Rows, _NS
 
 
 def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, dup_rows=0, out_gn=None):
@@ -138,13 +139,19 @@ def emit_ff(plan, tok, ln_g, ln_b, ff1, ff1_b, ff2, ff2_b, a, M, C, stream=None,
 
 
 def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared_half=False, ctx_img=None, pre=None, post=None,
-                     tok_stat=None, z=None, out_gn=None):
+                     tok_stat=None, z=None, out_gn=None, rank1=None):
     """BasicTransformerBlock.forward (src/models/attention.py:479-526) in place on tok [n_seq*Lq][C]:
     h += attn1(LN1(h)); h += attn2(LN2(h), ctx); h += FF(LN3(h)).  ctx_kv: Rows [n_seq*L][2C] = [K | V] of the context.
     shared_half: the two halves of tok (the CFG halves of a denoising step) hold IDENTICAL rows on entry — everything up
     to the query projection of the cross-attention is then computed on the first half only and stored to both.
     tok_stat: row statistics of tok from the GEMM that wrote it (emit_gemm(stat=True)); with them, and below the chain
-    kernels' row count, the three LayerNorms are deferred into the epilogues of the GEMMs behind them (rcdm_gemm_lnx)."""
+    kernels' row count, the three LayerNorms are deferred into the epilogues of the GEMMs behind them (rcdm_gemm_lnx).
+    rank1 (emit_rank1_ctx): the context rows of every sequence OUTSIDE rank1.runs are all equal (the unseen
+    frames' semantic_stack output, stage2_batchtest_rcdms_model.py:117-132) — the softmax over equal scores is uniform, so
+    attn2 (attention.py:139-144,170-199) of such a sequence is its V row for EVERY query, and to_out(V row) + bias is one
+    row r per sequence.  At the chain kernels' row count the cross-attention runs on the full-rank runs only and the other
+    rows of its output buffer hold the V row already (written once per context); below it norm2 / to_q / the attention /
+    to_out run on the full-rank runs only and r rides in attn1.to_out's epilogue as a per-sequence row vector."""
     C, M = w.C, n_seq * Lq
     d_head = C // heads
     ns, Ms, dup = n_seq, M, 0
@@ -166,7 +173,7 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
     if not hasattr(w, "score_bound"):
         w.score_bound = attn_score_bound(w.pk, w.attn1_key, w.attn1_ln, heads)
     emit_flash_attn(plan, qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), ns, heads, Lq, Lq, d_head, ao.rows(0, Ms),
-                    wide=w.score_bound >= MSUB_SCORE_LIMIT)
+                    wide=w.score_bound >= MSUB_SCORE_LIMIT, bound=w.score_bound)
     chain_q = w.has_cross and w.ch_o1_q is not None and not shared_half and big
     # (below CHAIN_MIN_ROWS only: with more rows the N = C producers run on the ping-pong kernel, which has no statistics
     # epilogue — the b = 8 configuration measured 59.5 ms per step without and 60.0 with the deferred form at 40960 rows)
@@ -174,6 +181,33 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
     # statistics for norm2 -> attn2.to_q (also for the shared half of a big batch, which runs the separate launches on Ms rows)
     want_q2 = SW.LNX and (not big or (shared_half and Ms < CHAIN_MIN_ROWS)) and w.has_cross and w.lnx_q2 is not None
     st = None
+    if rank1 is not None:
+        assert w.has_cross and ctx_img is None and (big or not shared_half)
+    if rank1 is not None and not big:
+        # the rank-1 sequences: tok += r_i here (their attn2 does not depend on the query), statistics for norm2 (full-rank
+        # rows) AND, for the rows no later launch touches, norm3
+        st = emit_gemm(plan, ao, w.o1, C, C, tok, bias=w.o1_b, residual=tok, rowvec=(rank1.rtab, 0, C, Lq),
+                       stat=want_q2 or want_ff)
+        qc = plan.rows("qkv", M, C)
+        for (i0, i1), img in zip(rank1.runs, rank1.imgs):
+            r0, n = i0 * Lq, (i1 - i0) * Lq
+            if st is not None and w.lnx_q2 is not None and gemm_lnx_ok(n, C, C, tok.ld, qc.ld):
+                emit_gemm(plan, tok.rows(r0, n), w.lnx_q2.W, C, C, qc.rows(r0, n), bias=w.lnx_q2.b, lnx=(st, w.lnx_q2.S),
+                          stat_row0=r0)
+            else:
+                emit_layernorm(plan, tok.rows(r0, n), w.ln[1][0], w.ln[1][1], a.rows(r0, n))
+                emit_gemm(plan, a.rows(r0, n), w.q2, C, C, qc.rows(r0, n), bias=w.q2_b)
+            emit_xattn(plan, qc.rows(r0, n), img, i1 - i0, heads, Lq, L, d_head, ao.rows(r0, n))
+            if st is not None:   # the rewritten rows' statistics go into the same buffer (None: no tile with its slot count)
+                st = emit_gemm(plan, ao.rows(r0, n), w.o2, C, C, tok.rows(r0, n), bias=w.o2_b, residual=tok.rows(r0, n),
+                               stat_into=st, stat_row0=r0)
+            else:
+                emit_gemm(plan, ao.rows(r0, n), w.o2, C, C, tok.rows(r0, n), bias=w.o2_b, residual=tok.rows(r0, n))
+        # (st None: some run had no tile with the buffer's slot count — norm3 then takes the stand-alone launch in emit_ff)
+        assert w.geglu
+        emit_ff(plan, tok, w.ln[2][0], w.ln[2][1], w.ff1, w.ff1_b, w.ff2, w.ff2_b, a, M, C, stream=w.ff_stream,
+                tok_stat=st, lnx=w.lnx_ff, z=z, out_gn=out_gn)
+        return
     if not chain_q:
         st = emit_gemm(plan, ao.rows(0, Ms), w.o1, C, C, tok.rows(0, Ms), bias=w.o1_b, residual=tok.rows(0, Ms), dup_rows=dup,
                        stat=want_q2 or (want_ff and not w.has_cross))
@@ -188,7 +222,12 @@ def emit_basic_block(plan, w, tok, n_seq, Lq, heads, a, ctx_kv=None, L=0, shared
         else:
             emit_layernorm(plan, tok.rows(0, Ms), w.ln[1][0], w.ln[1][1], a.rows(0, Ms))
             emit_gemm(plan, a.rows(0, Ms), w.q2, C, C, qc.rows(0, Ms), bias=w.q2_b, dup_rows=dup)
-        if ctx_img is not None:   # short context: the per-context fragment image (emit_ctx_kv), scores in registers
+        if rank1 is not None:     # (chain kernels' row count) the other rows of rank1.ao hold their sequence's V row already
+            for (i0, i1), img in zip(rank1.runs, rank1.imgs):
+                emit_xattn(plan, qc.rows(i0 * Lq, (i1 - i0) * Lq), img, i1 - i0, heads, Lq, L, d_head,
+                           rank1.ao.rows(i0 * Lq, (i1 - i0) * Lq))
+            ao = rank1.ao
+        elif ctx_img is not None:   # short context: the per-context fragment image (emit_ctx_kv), scores in registers
             emit_xattn(plan, qc, ctx_img, n_seq, heads, Lq, L, d_head, ao)
         else:
             emit_flash_attn(plan, qc, ctx_kv.cols(0, C), ctx_kv.cols(C, C), n_seq, heads, Lq, L, d_head, ao)
@@ -219,7 +258,8 @@ def ffz_rows(plan, w, M, C, x, out):
     return None, plan.rows("tok", M, C)
 
 
-def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_half=False, ctx_img=None, out_gn=None):
+def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_half=False, ctx_img=None, out_gn=None,
+                     rank1=None):
     """Transformer3DModel.forward + BasicTransformerBlock.forward (src/models/attention.py:318-365,479-526).
     ctx_kv: Rows [n_img*L][2C] = [K | V] projections of the context for this site (computed per context).
     shared_half: see emit_basic_block (x holds identical halves; both halves of `out` are still written in full)."""
@@ -241,7 +281,7 @@ def emit_transformer(plan, w, x, geo, ctx_kv, L, heads, out, groups=32, shared_h
     post = (w.ch_o2_ffz, x, w.proj_out_b, out) if (getattr(w, "ch_o2_ffz", None) is not None and w.has_cross and
                                                    g.M >= CHAIN_MIN_ROWS) else None
     emit_basic_block(plan, w, tok, g.n_img, g.hw, heads, a, ctx_kv, L, shared_half=shared_half, ctx_img=ctx_img, pre=pre,
-                     post=post, tok_stat=tok_stat, z=z, out_gn=out_gn)
+                     post=post, tok_stat=tok_stat, z=z, out_gn=out_gn, rank1=rank1)
     if post is None and z is None:
         emit_gemm(plan, tok, w.proj_out, C, C, out, bias=w.proj_out_b, residual=x, gn=out_gn)
 
@@ -253,6 +293,66 @@ def emit_ctx_kv(plan, w, ctx16, ctx_kv, n_seq=0, L=0, heads=0):
     if heads and 0 < L <= XATTN_MAX_KEYS:
         return emit_xattn_pack(plan, ctx_kv.cols(0, w.C), ctx_kv.cols(w.C, w.C), n_seq, heads, L, w.C // heads)
     return None
+
+
+def full_rank_runs(ctx):
+    """Maximal runs [(i0, i1), ...] of images of ctx (n_img, L, D) whose L context rows are NOT all bit-identical; the
+    images outside them are the rank-1 ones.  One comparison on the device + one small copy to the host; NaN
+    rows compare unequal, i.e. count as full rank (the general path)."""
+    full = (~(ctx == ctx[:, :1, :]).all(dim=2).all(dim=1)).tolist()
+    runs, i = [], 0
+    while i < len(full):
+        if full[i]:
+            j = i
+            while j < len(full) and full[j]:
+                j += 1
+            runs.append((i, j))
+            i = j
+        else:
+            i += 1
+    return tuple(runs)
+
+
+def emit_rank1_ctx(ctx_plan, plan, w, kv, geo, L, heads, runs, site):
+    """Per-context part of the rank-1-context plan of ONE cross-attention site (run by UNetProgram.set_context, not per
+    step): the fragment images of the full-rank runs, and for the images outside `runs` either — at the chain kernels' row
+    count — their V row written to every row of the site's own cross-attention output buffer, or — below it — the table
+    r[i] = to_out(V row of image i) + bias (zero rows for the full-rank images) that attn1.to_out's epilogue adds.
+    Returns what emit_basic_block takes as rank1.  kv: Rows [n_img * L][2C] = [K | V] of the context (emit_ctx_kv)."""
+    C, n_img, hw = w.C, geo.n_img, geo.hw
+    d_head = C // heads
+    r1 = _NS(runs=tuple(runs), imgs=[], rtab=None, ao=None)
+    for i0, i1 in runs:
+        sub = kv.rows(i0 * L, (i1 - i0) * L)
+        r1.imgs.append(emit_xattn_pack(ctx_plan, sub.cols(0, C), sub.cols(C, C), i1 - i0, heads, L, d_head))
+    in_run = [any(i0 <= i < i1 for i0, i1 in runs) for i in range(n_img)]
+    low = torch.tensor([i for i in range(n_img) if not in_run[i]], dtype=torch.long, device=plan.device)   # the rank-1 images
+    high = torch.tensor([i for i in range(n_img) if in_run[i]], dtype=torch.long, device=plan.device)
+    plan.keep += [low, high]
+
+    def kv_view():
+        return kv.buf.t.view(torch.float16)[kv.off:kv.off + n_img * L * kv.ld].view(n_img, L, kv.ld)
+
+    if geo.M >= CHAIN_MIN_ROWS:
+        r1.ao = plan.rows(f"xattn_out{site}", geo.M, C, unique=True)
+
+        def fill():   # (torch's current stream = the program's stream inside set_context)
+            ao_t = r1.ao.buf.t.view(torch.float16)[:geo.M * C].view(n_img, hw, C)
+            ao_t[low] = kv_view()[low, 0, C:2 * C][:, None, :].expand(-1, hw, -1)
+        ctx_plan.add(fill, f"rank1_fill M={geo.M} C={C}")
+    else:
+        r16 = plan.rows(f"rank1_r16_{site}", n_img, C, unique=True)
+        r1.rtab = torch.zeros(n_img, C, dtype=torch.float32, device=plan.device)
+        plan.keep.append(r1.rtab)
+        vrow = Rows(kv.buf, kv.off + C, n_img, C, L * kv.ld)    # row i = the V row of image i's first context token
+        emit_gemm(ctx_plan, vrow, w.o2, C, C, r16, bias=w.o2_b)
+
+        def table():
+            t = r16.buf.t.view(torch.float16)[:n_img * C].view(n_img, C).float()
+            t[high] = 0.0
+            r1.rtab.copy_(t)
+        ctx_plan.add(table, f"rank1_table n={n_img} C={C}")
+    return r1
 
 
 def emit_motion(plan, w, x, geo, heads, out, groups=32, prior_state=False, out_gn=None):

@@ -34,11 +34,15 @@ def assert_no_pending_gn(plan, who):
 
 
 def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geglu=False, scale=1.0, split_k=0,
-              gelu=False, dup_rows=0, stat=False, lnx=None, gn=None):
+              gelu=False, dup_rows=0, stat=False, lnx=None, gn=None, stat_into=None, stat_row0=0):
     """out[M][N or N/2] = epi(A[M][K] W[N][K]^T); rowvec = (tensor, elem_offset, ldt, rows_per_sample).
     Deferred LayerNorm (rcdm_gemm_lnx): stat=True — also write the row statistics of the stored rows and RETURN their handle
     (None when this shape has no statistics-producing launch: the caller then emits the stand-alone LayerNorm);
-    lnx=(handle, S) — A holds the RAW rows whose LayerNorm this GEMM consumes, Wt / bias carry gamma / beta (Packer.lnx_*)."""
+    lnx=(handle, S) — A holds the RAW rows whose LayerNorm this GEMM consumes, Wt / bias carry gamma / beta (Packer.lnx_*).
+    Row subsets (the rank-1-context plan): stat_row0 — A / out are rows [stat_row0, stat_row0 + M) of the tensor the
+    statistics handles index; stat_into=handle — write this launch's statistics INTO an earlier producer's buffer (its
+    slot count, its plane stride: the rows this launch rewrites get new statistics, the others keep theirs) and return
+    that handle, or None when the library has no tile with that slot count for this shape (rcdm_gemm_lnx_parts_ok)."""
     epi = 0
     if bias is not None:
         epi |= hip.EPI_BIAS
@@ -53,7 +57,13 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
     d = hip.GemmDesc(A.M, N, K, A.ld, out.ld, residual.ld if residual is not None else 0, epi,
                      rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k, dup_rows)
     handle, x = None, None
-    if stat and SW.LNX and not geglu and not hip.gemm_lnx_workspace_bytes(d, producer=True, consumer=lnx is not None):
+    if stat_into is not None:
+        assert stat_into.C == N and stat_into.M >= stat_row0 + A.M and not dup_rows
+        if (not geglu and hip.gemm_lnx_parts_ok(d, stat_into.parts, consumer=lnx is not None) and
+                not hip.gemm_lnx_workspace_bytes(d, producer=True, consumer=lnx is not None)):
+            assert stat_into.gen == getattr(plan, "rowstat_gen", 0), "the statistics buffer was reused since"
+            handle = stat_into
+    elif stat and SW.LNX and not geglu and not hip.gemm_lnx_workspace_bytes(d, producer=True, consumer=lnx is not None):
         parts = hip.gemm_stat_parts(d, consumer=lnx is not None)   # (asked with the flags the launch will carry)
         if 0 < parts <= LNX_MAX_PARTS:
             # the statistics of ALL producers live in one scratch buffer: a handle carries the generation it was written in,
@@ -72,7 +82,7 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
     rv_t, rv_off = (rowvec[0], rowvec[1]) if rowvec else (None, 0)
     if lnx is not None:
         assert not wsb, "deferred LayerNorm consumer cannot be a split-K launch (gemm_lnx_ok)"
-        assert lnx[0].C == K and lnx[0].M >= A.M
+        assert lnx[0].C == K and lnx[0].M >= stat_row0 + A.M
         # (a call that is consumer AND producer reads its rows' statistics at kernel start and writes the new ones in its
         # epilogue, into the same buffer: legal only because both sides index it by the same rows of the same launch)
         assert lnx[0].gen >= getattr(plan, "rowstat_gen", 0) - (1 if handle is not None else 0), \
@@ -90,8 +100,8 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
                             ws.ptr, ws.nbytes, hand[1].ptr, hand[1].nbytes)
             return
         if x is not None:
-            x.stat_out = handle.buf.ptr if handle is not None else 0
-            x.stat_in = lnx[0].buf.ptr if lnx is not None else 0
+            x.stat_out = handle.buf.ptr + 8 * stat_row0 if handle is not None else 0     # slot-major planes of float2 per row
+            x.stat_in = lnx[0].buf.ptr + 8 * stat_row0 if lnx is not None else 0
             hip.gemm_lnx(d, x, A.ptr, Wt.data_ptr(), bptr, rvp, residual.ptr if residual is not None else 0, out.ptr,
                          ws.ptr, ws.nbytes)
             return
@@ -100,6 +110,8 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
              + (" gnstat" if hand is not None else ""))
     plan.keep += [Wt, bias, rv_t, x, lnx[1] if lnx else None]
     plan.op_weights[len(plan.ops) - 1] = Wt
+    if lnx is not None:
+        plan.lnx_sites.append((len(plan.ops) - 1, A, lnx[1], plan.tags[-1]))
     plan.n_launch += 2 if wsb else 1
     if hand is not None:
         plan.gn_ready = dict(n_ops=len(plan.ops), key=out.ptr_key(), M=out.M, C=N, gn=gn)
@@ -212,14 +224,17 @@ def emit_layernorm(plan, x, gamma, beta, out, pe=None, rows_per_frame=1, frames=
     plan.n_launch += 1
 
 
-def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out, wide=False):
+def emit_flash_attn(plan, q, k, v, batch, heads, Lq, Lk, d_head, out, wide=False, bound=None):
     """wide: the caller has no bound |scaled score| < 2^15 for this site (rcdm.h, rcdm_flash_attn): the fp32-argument softmax
-    kernel is used where the d = 40 kernel would take its softmax argument from the matrix pipe (attn_score_bound)."""
+    kernel is used where the d = 40 kernel would take its softmax argument from the matrix pipe (attn_score_bound).
+    bound: that weight-norm bound, recorded with the site for numerics_report."""
     d = hip.AttnDesc(batch, heads, Lq, Lk, d_head, q.ld, k.ld, v.ld, out.ld, d_head ** -0.5, hip.ATTN_WIDE_RANGE if wide else 0)
 
     def op():
         hip.flash_attn(d, q.ptr, k.ptr, v.ptr, out.ptr)
     plan.add(op, f"flash_attn B={batch} H={heads} Lq={Lq} Lk={Lk} d={d_head}")
+    if bound is not None:
+        plan.attn_sites.append((len(plan.ops) - 1, plan.tags[-1], float(bound), bool(wide), q, k, heads, d_head))
     plan.n_launch += 1
 
 

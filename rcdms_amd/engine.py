@@ -17,13 +17,14 @@ story).  The parts (round 6: one module each, this file only re-exports them):
 Data layout in HBM: every activation is channels-last f16 rows X[(b f y x)][C] with an explicit row
 stride; torch is used for device memory, streams, host<->device copies and the one-time pack-time weight algebra —
 nothing torch computes is on the per-step path."""
+from . import switches as SW                                                                         # noqa: F401
 from .plan import Buf, Geo, Plan, Rows, _NS                                                          # noqa: F401
 from .emit_ops import (LNX_MAX_PARTS, XATTN_MAX_KEYS, emit_conv3x3, emit_flash_attn, emit_flash_attn_masked,   # noqa: F401
                        emit_gemm, emit_groupnorm, emit_groupnorm_stats, emit_layernorm, emit_temporal_attn,
                        emit_upsample_conv, emit_xattn, emit_xattn_pack, gemm_lnx_ok)
 from .packer import (MSUB_SCORE_LIMIT, Packer, attn_score_bound, pack_attention, pack_basic_block, pack_motion,   # noqa: F401
                      pack_resnet, pack_transformer)
-from .emit_blocks import (CHAIN_MIN_ROWS, emit_basic_block, emit_ctx_kv, emit_ff, emit_motion, emit_resnet,    # noqa: F401
-                          emit_rowchain, emit_transformer, ffz_rows)
+from .emit_blocks import (CHAIN_MIN_ROWS, emit_basic_block, emit_ctx_kv, emit_ff, emit_motion, emit_rank1_ctx,   # noqa: F401
+                          emit_resnet, emit_rowchain, emit_transformer, ffz_rows, full_rank_runs)
 from .unet_program import CIN_PAD, COUT_PAD, UNetProgram                                             # noqa: F401
 from .eager import ncfhw_from_rows, rows_from_ncfhw, run_block, run_tokens                           # noqa: F401

@@ -90,6 +90,7 @@ SYMBOLS = {
     "rcdm_gemm_ln": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(LnFuse), _P, _P, _P, _P, _P, _P]),
     "rcdm_gemm_stat_parts": (C.c_int, [C.POINTER(GemmDesc)]),
     "rcdm_gemm_lnx_stat_parts": (C.c_int, [C.POINTER(GemmDesc), _I]),
+    "rcdm_gemm_lnx_parts_ok": (C.c_int, [C.POINTER(GemmDesc), _I, _I]),
     "rcdm_gemm_lnx_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc), _I, _I]),
     "rcdm_set_groupnorm_fold": (C.c_int, [_I]),
     "rcdm_gemm_lnx": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(Lnx), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -318,6 +319,10 @@ def gemm_stat_parts(desc, consumer=False):
     if consumer:
         return int(load().rcdm_gemm_lnx_stat_parts(C.byref(desc), 1))
     return int(load().rcdm_gemm_stat_parts(C.byref(desc)))
+
+
+def gemm_lnx_parts_ok(desc, parts, consumer=False):
+    return bool(load().rcdm_gemm_lnx_parts_ok(C.byref(desc), int(parts), int(bool(consumer))))
 
 
 def gemm_lnx_workspace_bytes(desc, producer=False, consumer=False):

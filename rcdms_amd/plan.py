@@ -8,10 +8,11 @@ import torch
 
 class Buf:
     """A device buffer whose size is the max over all requests made while planning."""
-    __slots__ = ("name", "nbytes", "t")
+    __slots__ = ("name", "nbytes", "t", "f16")
 
     def __init__(self, name, nbytes):
         self.name, self.nbytes, self.t = name, int(nbytes), None
+        self.f16 = False    # holds f16 activation rows (Plan.rows): what numerics.numerics_report scans for range
 
     @property
     def ptr(self):
@@ -51,6 +52,8 @@ class Plan:
         self.keep = []  # tensors that must outlive the plan (packed weights etc.)
         self.n_launch = 0
         self.op_weights = {}   # op index -> weight tensor of a GEMM / conv op (tools/prefetch_bound.py)
+        self.lnx_sites = []    # deferred-LayerNorm consumers: (op index, A rows, colsum S, tag)          [numerics_report]
+        self.attn_sites = []   # self-attention sites: (op index, tag, weight-norm score bound, wide flag, q rows, k rows, heads, d)
 
     def scratch(self, name, nbytes):
         b = self.bufs.get(name)
@@ -69,6 +72,7 @@ class Plan:
     def rows(self, name, M, C, ld=None, unique=False):
         ld = ld or C
         buf = (self.new if unique else self.scratch)(name, M * ld * 2)
+        buf.f16 = True
         return Rows(buf, 0, M, C, ld)
 
     def materialize(self):

@@ -9,12 +9,13 @@ touches a parameter.  Generalised over the reference's hard-coded batch 1 / 64x6
 import torch
 
 from . import hip
-from .engine import CIN_PAD
+from . import switches as SW
+from .engine import CIN_PAD, full_rank_runs
 
 
 class DenoiseLoop:
     def __init__(self, unet, stories, frames, height, width, ctx_len, guidance_scale, scheduler, num_steps,
-                 share_cfg_prefix=True, cfg_split=None):
+                 share_cfg_prefix=True, cfg_split=None, rank1_context=True):
         """cfg_split (rcdms_amd.dist.CfgSplit or anything with .half and .allgather(send_ptr, recv_ptr, nbytes)): the
         two-GPUs-per-story latency mode — this rank evaluates only CFG half `half` of the UNet (batch S instead of 2S),
         the halves' noise predictions are all-gathered inside the step graph and every rank applies the same CFG +
@@ -80,17 +81,20 @@ class DenoiseLoop:
         if cfg_split is not None and self.reps != 2:
             raise ValueError("cfg_split needs classifier-free guidance (guidance_scale > 1)")
         self.share_allowed = share_cfg_prefix and cfg_split is None
+        self.rank1_allowed = bool(rank1_context) and SW.RANK1_CTX
         self._variants = {}
         self._v = None
 
-    def _select(self, share):
-        v = self._variants.get(share)
+    def _select(self, share, runs=None):
+        """share: the shared-CFG-prefix plan; runs: the full-rank image runs of the context (engine.full_rank_runs) when some
+        images' context rows are all equal — the rank-1-context plan — else None."""
+        v = self._variants.get((share, runs))
         if v is None:
             S, R, f, H, W = self.S, self.reps, self.f, self.H, self.W
             if self.split is not None:
                 # one CFG half here: batch rows [half * S, (half + 1) * S) of the reference's cat([latents] * 2)
                 half, b = self.split.half, S
-                p = self.unet.program(b, f, H, W, self.ctx_len, shared_prefix=False)
+                p = self.unet.program(b, f, H, W, self.ctx_len, shared_prefix=False, rank1_runs=runs)
                 eps = p.eps_out
                 nbytes = eps.M * eps.ld * 2
                 self.eps_full = torch.empty(2 * eps.M, eps.ld, dtype=torch.float16, device=self.device)
@@ -109,7 +113,7 @@ class DenoiseLoop:
                 ]
             else:
                 b = R * S
-                p = self.unet.program(b, f, H, W, self.ctx_len, shared_prefix=share)
+                p = self.unet.program(b, f, H, W, self.ctx_len, shared_prefix=share, rank1_runs=runs)
                 # the timestep-embedding chain and all time_emb_proj rows for the T steps of the schedule, once
                 table = p.time_table(self.timesteps.tolist())
                 pre = [
@@ -121,8 +125,9 @@ class DenoiseLoop:
                     lambda: self._sched_step(p.eps_out.ptr, p.eps_out.ld),
                     lambda: hip.advance_step(self.step_dev.data_ptr()),
                 ]
-            v = self._variants[share] = dict(prog=p, pre=pre, post=post, graph=None)
+            v = self._variants[(share, runs)] = dict(prog=p, pre=pre, post=post, graph=None)
         self.shared = share
+        self.rank1_runs = v["prog"].rank1_runs
         self._v = v
 
     def _sched_step(self, eps_ptr, ld):
@@ -171,10 +176,17 @@ class DenoiseLoop:
         # the CFG halves share their UNet input exactly when mask and masked latents repeat (the latents always do)
         share = (self.share_allowed and R == 2 and bool(torch.equal(self.mask[:S], self.mask[S:]))
                  and bool(torch.equal(self.masked[:S], self.masked[S:])))
-        self._select(share)
         if self.split is not None:
             n = S * self.f                          # context rows per CFG half: (R*S*f, L, D), unconditional half first
             ctx = ctx[self.split.half * n:(self.split.half + 1) * n]
+        # images whose L context rows are all equal (the reference's unseen frames): their cross-attention is
+        # query-independent — the plan variant that skips it, selected per context the way the shared prefix is per story
+        runs = None
+        if self.rank1_allowed:
+            runs = full_rank_runs(ctx.detach().to(self.device))
+            if sum(i1 - i0 for i0, i1 in runs) >= ctx.shape[0]:
+                runs = None
+        self._select(share, runs)
         self.prog.set_context(ctx, force=True)   # ~3 MB + 16 small GEMMs per story: never trust a cache here
         self.step_dev.zero_()
         self._pndm_next = 0

@@ -39,6 +39,8 @@ def procedural_tensor(name, shape, seed=0, style="unit"):
     shape = tuple(int(s) for s in shape)
     if name.endswith("pos_encoder.pe"):
         return sinusoid_table(shape[2], shape[1])
+    if style == "sdlike":
+        return _sdlike_tensor(name, shape, seed)
     if style not in ("unit", "skewed"):
         raise ValueError(f"unknown weight style {style!r}")
     g = _rng(name, seed)
@@ -63,6 +65,34 @@ def procedural_tensor(name, shape, seed=0, style="unit"):
     return torch.from_numpy(np.ascontiguousarray(x))
 
 
+SDLIKE_OUTLIER_CHANNELS, SDLIKE_OUTLIER_GAIN, SDLIKE_QK_GAIN = 2, (50.0, 100.0), 5.0
+
+
+def _sdlike_tensor(name, shape, seed):
+    """style "sdlike" — the third weight family: the unit-gain family plus the two features of trained
+    Stable-Diffusion weights that decide whether an f16 path survives them:
+      * "massive activations": conv1 and conv2 of every ResnetBlock3D have SDLIKE_OUTLIER_CHANNELS output channels whose
+        kernel (and bias) carry a gain drawn from U[50, 100) — channels 50-100x above their neighbours feeding the
+        GroupNorm behind them (the group that holds one is dominated by it) and accumulating on the residual stream;
+      * sharp attention: to_q and to_k of every spatial self-attention (attn1) carry a gain of SDLIKE_QK_GAIN each, so
+        the logits are 25x the unit family's — in the hundreds at the tails, a near-one-hot softmax.
+    Everything else as "unit".  (Trained checkpoints are not available here; this family is a stress shape, not a model.)"""
+    x = procedural_tensor(name, shape, seed, "unit").numpy().copy()
+    owner = name.rsplit(".", 1)[0]
+    # ResnetBlock3D.conv1 / conv2 (resnet.py:147,167) only: conv1 feeds norm2, conv2 ADDS to the residual stream.  The layers
+    # ON the residual path (conv_shortcut, the samplers' conv, conv_in) keep unit gain — outlier gains there multiply from
+    # level to level (75^6 over the six samplers: the reference itself reaches 1e12) instead of modelling outlier channels
+    if owner.rsplit(".", 1)[-1] in ("conv1", "conv2") and name.endswith((".weight", ".bias")):
+        g = _rng(owner + "#sdlike", seed)          # weight and bias of one layer share their outlier channels
+        ch = g.choice(shape[0], size=min(SDLIKE_OUTLIER_CHANNELS, shape[0]), replace=False)
+        gain = g.uniform(*SDLIKE_OUTLIER_GAIN, size=len(ch)).astype(np.float32)
+        for c, a in zip(ch, gain):
+            x[c] *= a
+    elif ".attn1.to_q.weight" in name or ".attn1.to_k.weight" in name:
+        x *= SDLIKE_QK_GAIN
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
 def normal_tensor(name, shape, seed=0):
     """Standard-normal test INPUT named `name` (platform-stable Philox stream, like the weights)."""
     g = _rng(name, seed)
@@ -82,11 +112,15 @@ def procedural_state_dict(shapes, seed=0, style="unit"):
     return {k: procedural_tensor(k, tuple(v), seed, style) for k, v in shapes.items()}
 
 
-def synthetic_story(stories=1, frames=5, latent_hw=(64, 64), ctx_len=85, ctx_dim=768, cfg=True, seed=42):
+def synthetic_story(stories=1, frames=5, latent_hw=(64, 64), ctx_len=85, ctx_dim=768, cfg=True, seed=42, structure="dense"):
     """CPU-seeded inputs of the denoising loop for `stories` stories.
     Returns dict(latents (S,4,f,h,w), mask (R*S,1,f,h,w), masked_latents (R*S,4,f,h,w), ctx (R*S*f, L, D)),
     R = 2 with CFG.  mask = [1,0,0,0,0] per story (first frame seen), masked latents of unseen frames are a
-    constant (the stand-in for the VAE latent of a black frame, RCDMs_pipeline.py:427-432)."""
+    constant (the stand-in for the VAE latent of a black frame, RCDMs_pipeline.py:427-432).
+    structure: "dense" (the headline workload, SURVEY §8d: every context row N(0,1)) or "reference" — the row structure the
+    reference's context builders really produce for this mask (RCDMs_pipeline.py:444-450, SURVEY F5 / F6): the seen frames'
+    rows first ([u0, c0] per story: fine_stack output, dense), then the unseen frames' ([u1..u4, c1..c4]: semantic_stack
+    has ONE key / value token, stage2_batchtest_rcdms_model.py:117-132, so all L rows of such an image are one vector)."""
     g = torch.Generator().manual_seed(seed)
     h, w = latent_hw
     reps = 2 if cfg else 1
@@ -96,6 +130,11 @@ def synthetic_story(stories=1, frames=5, latent_hw=(64, 64), ctx_len=85, ctx_dim
     mask = torch.zeros(stories, 1, frames, h, w)
     mask[:, :, 0] = 1.0
     ctx = torch.randn(reps * stories * frames, ctx_len, ctx_dim, generator=g)
+    if structure == "reference":
+        n_seen = reps * stories * 1                      # mask = [1, 0, 0, 0, 0]: one seen frame per (CFG half, story)
+        ctx[n_seen:] = ctx[n_seen:, :1, :].expand(-1, ctx_len, -1).clone()
+    elif structure != "dense":
+        raise ValueError(f"structure {structure!r}")
     return dict(latents=lat, mask=torch.cat([mask] * reps), masked_latents=torch.cat([ml] * reps), ctx=ctx)
 
 

@@ -6,8 +6,9 @@ the reference recomputes them every step, attention.py:139-141), graph capture a
 import torch
 
 from . import hip
-from .emit_blocks import CHAIN_MIN_ROWS, emit_ctx_kv, emit_motion, emit_resnet, emit_transformer
-from .emit_ops import emit_conv3x3, emit_groupnorm, emit_upsample_conv
+from .emit_blocks import (CHAIN_MIN_ROWS, emit_ctx_kv, emit_motion, emit_rank1_ctx, emit_resnet, emit_transformer,
+                          full_rank_runs)
+from .emit_ops import XATTN_MAX_KEYS, emit_conv3x3, emit_groupnorm, emit_upsample_conv
 from .packer import Packer, pack_motion, pack_resnet, pack_transformer
 from .plan import Geo, Plan
 
@@ -18,11 +19,22 @@ COUT_PAD = 8   # conv_out writes 4 channels + 4 zero columns (16-byte rows)
 class UNetProgram:
     """Static launch plan of one UNet3DConditionModel.forward for fixed (b, f, H, W, L)."""
 
-    def __init__(self, cfg, sd, b, frames, H, W, L, device, shared_prefix=False):
+    def __init__(self, cfg, sd, b, frames, H, W, L, device, shared_prefix=False, rank1_runs=None):
         """shared_prefix: the caller guarantees that samples [0, b/2) and [b/2, b) of the input are IDENTICAL and differ
         only in their context rows (the two CFG halves of a denoising step: RCDMs_pipeline.py:481 duplicates the latents,
         mask and masked latents).  conv_in, the first ResNet block and the first transformer up to the cross-attention
         query are then evaluated once and stored to both halves — bit-identical to evaluating the half batch twice."""
+        # rank1_runs: None, or the maximal runs ((i0, i1), ...) of images whose context rows are NOT all equal (full_rank_runs);
+        # the caller guarantees — and set_context checks — that every image outside them has L identical context rows (SURVEY
+        # F6: the unseen frames' rows, RCDMs_pipeline.py:447-450): their cross-attention is query-independent and collapses to
+        # one row per (image, site), see emit_basic_block.  Selected per context the way shared_prefix is selected per story.
+        self.rank1_runs = None
+        if rank1_runs is not None:
+            runs = tuple((int(i0), int(i1)) for i0, i1 in rank1_runs)
+            if any(not (0 <= i0 < i1 <= b * frames) for i0, i1 in runs) or any(a[1] >= c[0] for a, c in zip(runs, runs[1:])):
+                raise hip.RcdmError(f"rank1_runs {runs}: not disjoint ascending runs of the {b * frames} images")
+            if sum(i1 - i0 for i0, i1 in runs) < b * frames and 0 < L <= XATTN_MAX_KEYS:
+                self.rank1_runs = runs      # (every image full rank, or a context too long for rcdm_xattn: the general plan)
         if shared_prefix and (b % 2 or cfg["down_block_types"][0] != "CrossAttnDownBlock3D"):
             raise hip.RcdmError("shared_prefix needs an even batch and a cross-attention first block")
         self.shared_prefix = bool(shared_prefix)
@@ -146,8 +158,17 @@ class UNetProgram:
             w = pack_transformer(pk, p, lnx=small or shared_half, ffz=small)
             kv = plan.rows(f"ctx_kv{site[0]}", geo.n_img * L, 2 * w.C, unique=True)
             site[0] += 1
-            img = emit_ctx_kv(ctx_plan, w, self.ctx16, kv, geo.n_img, L, heads)
-            emit_transformer(plan, w, x, geo, kv, L, heads, out, groups, shared_half=shared_half, ctx_img=img, out_gn=out_gn)
+            r1 = None
+            if self.rank1_runs is not None and not (shared_half and small):
+                # (below the chain kernels' row count the shared-prefix transformer stores one half's rows to both halves:
+                #  a per-image row cannot ride in that epilogue — this one site then keeps the general form)
+                emit_ctx_kv(ctx_plan, w, self.ctx16, kv)
+                r1 = emit_rank1_ctx(ctx_plan, plan, w, kv, geo, L, heads, self.rank1_runs, site[0] - 1)
+                img = None
+            else:
+                img = emit_ctx_kv(ctx_plan, w, self.ctx16, kv, geo.n_img, L, heads)
+            emit_transformer(plan, w, x, geo, kv, L, heads, out, groups, shared_half=shared_half, ctx_img=img, out_gn=out_gn,
+                             rank1=r1)
 
         def motion(p, x, geo, out, out_gn=None):
             emit_motion(plan, pack_motion(pk, p, n_attn, lnx=geo.M < CHAIN_MIN_ROWS), x, geo, mheads, out, groups, out_gn=out_gn)
@@ -280,6 +301,12 @@ class UNetProgram:
             raise hip.RcdmError(f"encoder_hidden_states shape {tuple(ctx.shape)} != "
                                 f"{(n_img, self.L, self.cfg['cross_attention_dim'])}")
         src = ctx.detach().to(self.device, torch.float32).contiguous()
+        if self.rank1_runs is not None:
+            inside = lambda i: any(i0 <= i < i1 for i0, i1 in self.rank1_runs)
+            bad = [i for i0, i1 in full_rank_runs(src) for i in range(i0, i1) if not inside(i)]
+            if bad:
+                raise hip.RcdmError(f"this launch plan was built for contexts whose images outside {self.rank1_runs} have L "
+                                    f"identical rows; images {bad} of this context do not (select the plan with full_rank_runs)")
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):

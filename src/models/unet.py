@@ -228,7 +228,7 @@ class UNet3DConditionModel(nn.Module):
             module.gradient_checkpointing = value
 
     # ---- weights changed -> drop cached launch plans -------------------------------------------------------
-    MAX_LIVE_PLANS = 3   # geometries kept packed at once (2.55 GB of f16 weights + ~3.5 GB of buffers each)
+    MAX_LIVE_PLANS = 4   # plans (geometry x shared-prefix x rank-1-context variant) kept packed at once (2.55 GB of f16 weights + ~3.5 GB of buffers each)
 
     def _invalidate(self):
         self._programs = {}
@@ -259,26 +259,60 @@ class UNet3DConditionModel(nn.Module):
             motion_attention_blocks=len(mk.get("attention_block_types", ("Temporal_Self", "Temporal_Self"))),
             mid_block_scale_factor=c.mid_block_scale_factor)
 
-    def program(self, b, frames, H, W, L, shared_prefix=False):
-        """The cached static launch plan for one input geometry (shared_prefix: see rcdms_amd.engine.UNetProgram)."""
+    def program(self, b, frames, H, W, L, shared_prefix=False, rank1_runs=None):
+        """The cached static launch plan for one input geometry (shared_prefix, rank1_runs: see rcdms_amd.engine.UNetProgram)."""
         dev = self.device
         if dev.type != "cuda":
             raise hip.RcdmError("UNet3DConditionModel runs on MI355X only: move the model to a CUDA/HIP device "
                                 "(rcdms_amd has no CPU fallback)")
         if self.config.motion_module_decoder_only and self.config.use_motion_module:
             raise NotImplementedError("motion_module_decoder_only is not supported on the HIP path")
-        key = (b, frames, H, W, L, str(dev), bool(shared_prefix))
+        if rank1_runs is not None and (sum(i1 - i0 for i0, i1 in rank1_runs) >= b * frames or not engine.SW.RANK1_CTX):
+            rank1_runs = None       # every image full rank (or the fast path switched off): the general plan
+        key = (b, frames, H, W, L, str(dev), bool(shared_prefix), tuple(rank1_runs) if rank1_runs is not None else None)
         prog = self._programs.get(key)
         if prog is None:
             while len(self._programs) >= self.MAX_LIVE_PLANS:      # least recently used geometry goes first
                 self._programs.pop(next(iter(self._programs)))
             with torch.no_grad():
                 prog = engine.UNetProgram(self.engine_config(), self.state_dict(), b, frames, H, W, L, dev,
-                                          shared_prefix=shared_prefix)
+                                          shared_prefix=shared_prefix, rank1_runs=rank1_runs)
         else:
             self._programs.pop(key)
         self._programs[key] = prog                                  # (re)insert as most recently used
         return prog
+
+    def numerics_report(self, sample, timestep, encoder_hidden_states, verbose=True):
+        """Range / headroom report of the f16 HIP path for THESE weights on THIS input — run it once after
+        load_state_dict() of a real checkpoint (rcdms_amd/numerics.py says what is reported): per plan
+        buffer max |activation| against the f16 limit 65504, per self-attention site the weight-norm score bound and
+        whether the wide-range kernel was selected, per deferred-LayerNorm site max |mean rstd S|.  Non-finite values
+        anywhere raise RcdmError.  Arguments as forward() (unet.py:322-330); returns the report dict."""
+        from rcdms_amd.numerics import numerics_report
+        b, _, f, H, W = sample.shape
+        prog = self.program(b, f, H, W, encoder_hidden_states.shape[1], rank1_runs=self._context_runs(encoder_hidden_states))
+        rep = numerics_report(prog, sample, timestep, encoder_hidden_states)
+        if verbose:
+            print(rep["text"])
+        return rep
+
+    def _context_runs(self, ctx):
+        """Which images of this context have L identical rows (the reference's unseen frames,
+        RCDMs_pipeline.py:447-450) — decides the plan variant as rcdms_amd.engine.full_rank_runs does.  One device
+        comparison + a host read per NEW context tensor: the reference's loop passes the same tensor object at every
+        step (RCDMs_pipeline.py:488), so the answer is cached on (object, version)."""
+        if not engine.SW.RANK1_CTX:
+            return None
+        try:
+            ver = ctx._version
+        except RuntimeError:
+            ver = None
+        c = getattr(self, "_ctx_runs_cache", None)
+        if ver is not None and c is not None and c[0] is ctx and c[1] == ver:
+            return c[2]
+        runs = engine.full_rank_runs(ctx.detach())
+        self._ctx_runs_cache = (ctx, ver, runs) if ver is not None else None
+        return runs
 
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
                 encoder_hidden_states: torch.Tensor, class_labels: Optional[torch.Tensor] = None,
@@ -306,7 +340,7 @@ class UNet3DConditionModel(nn.Module):
             t = t.reshape(-1)
             if t.numel() != b:
                 raise ValueError("timestep must be a scalar or have one entry per batch element")
-        prog = self.program(b, f, H, W, encoder_hidden_states.shape[1])
+        prog = self.program(b, f, H, W, encoder_hidden_states.shape[1], rank1_runs=self._context_runs(encoder_hidden_states))
         out = prog.forward(sample, t, encoder_hidden_states)
         out = out.to(sample.dtype) if sample.dtype != torch.float32 else out
         if not return_dict:

@@ -3,12 +3,16 @@ context broadcast, result gather).  The denoising loop itself has no collective,
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 import torch.nn as nn
 
 from rcdms_amd.dist import broadcast_context, broadcast_module, gather_stories, split_stories
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_split_stories_matches_reference_split_list():
@@ -230,3 +234,33 @@ def test_cfg_split_step_world2():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, 0, 0, 1, 1, True), (1, 0, 1, 0, 1, True)]
+
+
+def test_watchdog_aborts_a_hung_phase():
+    """rcdms_amd.dist.Watchdog: a phase that never finishes (a peer that never arrives) ends the process with exit code 86 and
+    names the phase; a phase that finishes in time leaves no timer behind."""
+    import subprocess
+    import sys
+    import time
+    code = ("import time, sys; sys.path.insert(0, %r)\n"
+            "from rcdms_amd.dist import Watchdog\n"
+            "with Watchdog(5.0, 'fast phase'): pass\n"
+            "with Watchdog(0.5, 'rank 3: timed region'): time.sleep(30)\n" % ROOT)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 86, (r.returncode, r.stderr[-500:])
+    assert "rank 3: timed region" in r.stderr and "rcdm_comm_last_error" in r.stderr
+    assert time.time() - t0 < 25
+
+
+def test_build_verify_refuses_a_stale_library(monkeypatch):
+    """What the ranks that did not build call behind the build barrier (and what a node without hipcc relies on): the in-tree
+    library's stamp must be the stamp of THIS tree's sources."""
+    from rcdms_amd import build
+    assert build.verify() == build.LIB                       # the library built for this tree
+    monkeypatch.setattr(build, "_stamp", lambda: "0" * 64)
+    with pytest.raises(RuntimeError, match="other sources"):
+        build.verify()
+    monkeypatch.setattr(build, "HIPCC", "/nonexistent/hipcc")
+    with pytest.raises(RuntimeError, match="hipcc not found.*OTHER sources"):
+        build.build(verbose=False)

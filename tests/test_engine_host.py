@@ -39,3 +39,44 @@ def test_attn_score_bound_dominates_every_score():
         assert bound < 60 * max(smax, 1.0)            # ... and is not vacuous (Cauchy-Schwarz + Frobenius: a small factor)
         assert (bound >= MSUB_SCORE_LIMIT) == (wscale >= 300.0)
     assert attn_score_bound(_FakePacker(sd), "a.", None, heads) == float("inf")   # no LayerNorm in front: nothing bounds the rows
+
+
+def test_denoise_loop_refuses_non_ddim_timestep_lists():
+    """DenoiseLoop's fused DDIM step must not run on a scheduler whose timestep list is not DDIM's (a diffusers
+    PNDMScheduler object has alphas_cumprod but no plms_table(): N + 1 timesteps, the second one repeated) — and accepts the
+    product's own DDIM / PNDM classes.  Host logic only: the launch plan is built on first load()."""
+    import pytest
+    from rcdms_amd.sampler import DenoiseLoop
+    from rcdms_amd.scheduler import DDIMScheduler, PNDMScheduler
+
+    class FakeUNet:
+        device = torch.device("cpu")
+
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1)
+    lp = DenoiseLoop(FakeUNet(), 1, 5, 8, 8, 13, 2.0, DDIMScheduler(clip_sample=False, **kw), 10)
+    assert lp.T == 10 and not lp.pndm and tuple(lp.coef.shape) == (10, 4)
+    lp = DenoiseLoop(FakeUNet(), 1, 5, 8, 8, 13, 2.0, PNDMScheduler(skip_prk_steps=True, **kw), 10)
+    assert lp.T == 11 and lp.pndm
+
+    real = PNDMScheduler(skip_prk_steps=True, **kw)
+
+    class DiffusersLikePNDM:           # what `from diffusers import PNDMScheduler` hands the pipeline: no plms_table()
+        config = real.config
+        alphas_cumprod = real.alphas_cumprod
+        init_noise_sigma = 1.0
+
+        def set_timesteps(self, n, device=None):
+            real.set_timesteps(n)
+            self.timesteps = real.timesteps
+
+    with pytest.raises(NotImplementedError, match="not a DDIM schedule"):
+        DenoiseLoop(FakeUNet(), 1, 5, 8, 8, 13, 2.0, DiffusersLikePNDM(), 10)
+
+    class OddStride(DDIMScheduler):    # a DDIM-shaped object whose list does not have the constant stride
+        def set_timesteps(self, n, device=None):
+            super().set_timesteps(n, device)
+            self.timesteps = self.timesteps.clone()
+            self.timesteps[1] -= 3
+
+    with pytest.raises(NotImplementedError, match="not a DDIM schedule"):
+        DenoiseLoop(FakeUNet(), 1, 5, 8, 8, 13, 2.0, OddStride(clip_sample=False, **kw), 10)

@@ -136,7 +136,32 @@ def test_bench_two_ranks_share_one_gpu(hiplib):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and len(out["per_rank_ms"]) == 2 and len(out["devices"]) == 2
-    assert out["data"].startswith("INVALID (--share-gpu")
+    assert out["data"].startswith("INVALID (--share-gpu") and out["gathered_stories"] == 2
     assert out["config"]["parallelism"] == "story-replicas x2" and out["scaling"] == "weak"
     # value = the frames of BOTH ranks over the slower rank's time
     assert abs(out["value"] - 5 * 1 * 1 * 2 / (out["ms_per_step"] * 1e-3)) < 1e-3 * out["value"]
+
+
+def test_bench_eight_ranks_share_one_gpu(hiplib):
+    """Rehearsal of the driver's `--gpus 8` run on the one device a builder's box has (VERDICT r5 #5a): EIGHT ranks of
+    bench.py's real multi-rank path on device 0 (gloo in place of RCCL, a width-64 UNet so that eight launch plans fit) —
+    build by the node's first rank + stamp check on the seven others, broadcast_module of rank 0's weights, the shared
+    unconditional context rows broadcast from rank 0 (rcdms_amd.dist.broadcast_context, what north_star words as the RCCL
+    context broadcast), one story per rank, barrier / max-over-ranks timing, and the final gather with an UNEVEN story count
+    (--ragged: the odd ranks contribute none, so gather_stories' size exchange + padding runs on device tensors)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--share-gpu", "--width", "64", "--latent", "16",
+                        "--ctx-len", "13", "--steps", "2", "--warmup", "1", "--ddim-steps", "3", "--ragged", "--no-cpu-baseline",
+                        "--watchdog", "600"], capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and len(out["per_rank_ms"]) == 8 and len(out["devices"]) == 8
+    assert out["gathered_stories"] == 4, "ranks 0, 2, 4, 6 hand one story each to the gather"
+    assert out["data"].startswith("INVALID (")
+    assert out["config"]["parallelism"] == "story-replicas x8" and out["scaling"] == "weak"
+    assert abs(out["value"] - 5 * 1 * 2 * 8 / (2 * out["ms_per_step"] * 1e-3)) < 1e-3 * out["value"]

@@ -347,6 +347,18 @@ def test_denoise_loop_pndm_vs_oracle(hiplib):
     loop.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
     out2 = loop.run(use_graph=False).clone()
     assert torch.equal(out, out2)
+    # the PLMS step is stateful.  (a) a split run — eager steps, then the FIRST graphed run at start > 0, whose
+    # warm-up step must leave the multistep history alone — gives the one-piece result; (b) run(start) anywhere but where the
+    # previous run stopped (or 0) is refused
+    loop_b = DenoiseLoop(m, 1, 5, 16, 16, 13, 2.0, sched, 6)
+    loop_b.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+    loop_b.run(use_graph=False, start=0, steps=3)
+    out3 = loop_b.run(use_graph=True, start=3).clone()
+    assert torch.equal(out, out3), "the warm-up step of the first graph capture corrupted the PLMS history"
+    loop_b.load(s["latents"], s["mask"], s["masked_latents"], s["ctx"])
+    loop_b.run(start=0, steps=2)
+    with pytest.raises(ValueError, match="multistep history"):
+        loop_b.run(start=4)
 
 
 def test_story_batch_equals_single_stories(hiplib):

@@ -128,6 +128,46 @@ def test_tiny_unet_oracle(name):
     assert_close(y, g["y"])
 
 
+def test_tiny_unet_oracle_rank1_context():
+    """The structured context of SURVEY F6 (rows 2..9 of the (b f) order with L identical rows each): the oracle against the
+    reference's output on it, and the algebra the rank-1 plan of the HIP path rests on — for such an image attn2 does not
+    depend on the query, so a context of ONE row per rank-1 image (same vector) gives the same result."""
+    g = gold("unet_tiny_16_rank1ctx")
+    sd = weights("unet_tiny")
+    cfg = O.tiny_config(width=64, cross_dim=64, layers_per_block=2)
+    ctx = g["ctx"]
+    assert all(bool((ctx[i] == ctx[i, :1]).all()) == (i >= 2) for i in range(10))
+    s = synth.synthetic_story(stories=1, latent_hw=(16, 16), ctx_len=13, ctx_dim=64, seed=44, structure="reference")
+    assert torch.equal(s["ctx"], ctx)
+    y = O.unet_forward(sd, cfg, g["x"], torch.tensor(g["t"]), ctx)
+    assert_close(y, g["y"])
+    a = "down_blocks.1.attentions.0.transformer_blocks.0.attn2."
+    h = torch.randn(1, 64, 128, generator=torch.Generator().manual_seed(0))
+    o = O.attention_core(h @ sd[a + "to_q.weight"].t(), ctx[5:6] @ sd[a + "to_k.weight"].t(), ctx[5:6] @ sd[a + "to_v.weight"].t(), 8)
+    vrow = ctx[5, :1] @ sd[a + "to_v.weight"].t()
+    assert (o - vrow).abs().max() < 1e-5, "attn2 of a rank-1 context image is its V row for every query"
+
+
+def test_sdlike_weight_family_is_what_it_says():
+    """synth style "sdlike" (VERDICT r5 #6): two output channels of every ResnetBlock3D conv1 / conv2 at 50-100x gain
+    (weight and bias share the channels), 5x gain on attn1.to_q / to_k, nothing on the residual path."""
+    w = synth.procedural_tensor("up_blocks.1.resnets.0.conv2.weight", (64, 32, 3, 3), 9, "sdlike")
+    b = synth.procedural_tensor("up_blocks.1.resnets.0.conv2.bias", (64,), 9, "sdlike")
+    u = synth.procedural_tensor("up_blocks.1.resnets.0.conv2.weight", (64, 32, 3, 3), 9, "unit")
+    ratio = (w.flatten(1).norm(dim=1) / u.flatten(1).norm(dim=1))
+    hot = (ratio > 1.5).nonzero().flatten().tolist()
+    assert len(hot) == 2 and all(50.0 <= ratio[c] < 100.0 for c in hot)
+    ub = synth.procedural_tensor("up_blocks.1.resnets.0.conv2.bias", (64,), 9, "unit")
+    assert sorted((b / ub).abs().gt(1.5).nonzero().flatten().tolist()) == sorted(hot)
+    for name in ("up_blocks.1.resnets.0.conv_shortcut.weight", "down_blocks.0.downsamplers.0.conv.weight", "conv_in.weight"):
+        shp = (64, 32, 1, 1) if "shortcut" in name else (64, 32, 3, 3)
+        assert torch.equal(synth.procedural_tensor(name, shp, 9, "sdlike"), synth.procedural_tensor(name, shp, 9, "unit"))
+    q = "mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight"
+    assert torch.allclose(synth.procedural_tensor(q, (64, 64), 9, "sdlike"), 5.0 * synth.procedural_tensor(q, (64, 64), 9, "unit"))
+    k2 = "mid_block.attentions.0.transformer_blocks.0.attn2.to_k.weight"
+    assert torch.equal(synth.procedural_tensor(k2, (64, 64), 9, "sdlike"), synth.procedural_tensor(k2, (64, 64), 9, "unit"))
+
+
 def test_frames_are_coupled_and_batch_is_not():
     """SURVEY F2: perturbing one frame changes the others (cross-frame GroupNorm + temporal attention);
     perturbing one batch element leaves the other bit-identical."""
@@ -151,6 +191,23 @@ def test_full_unet_oracle_32():
     g = gold("unet_full_32")
     sd = weights("unet_full")
     s = synth.synthetic_story(stories=1, latent_hw=(32, 32), ctx_len=85, seed=42)
+    x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1)
+    with torch.no_grad():
+        y = O.unet_forward(sd, O.SD15_STAGE2_CONFIG, x, torch.tensor(g["t"]), s["ctx"])
+    assert_close(y, g["y"], tol=5e-4)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", ["unet_full_32_rank1ctx", "unet_full_32_sdlike"])
+def test_full_unet_oracle_32_round6_fixtures(name):
+    """The round-6 full-width fixtures (structured context; third weight family): oracle restatement vs the reference."""
+    g = gold(name)
+    if name.endswith("sdlike"):
+        sd = synth.procedural_state_dict(shapes_of(mirrored("unet_full")), int(g["seed"]), "sdlike")
+        s = synth.synthetic_story(stories=1, latent_hw=(32, 32), ctx_len=85, seed=int(g["story_seed"]))
+    else:
+        sd = weights("unet_full")
+        s = synth.synthetic_story(stories=1, latent_hw=(32, 32), ctx_len=85, seed=42, structure="reference")
     x = torch.cat([torch.cat([s["latents"]] * 2), s["mask"], s["masked_latents"]], dim=1)
     with torch.no_grad():
         y = O.unet_forward(sd, O.SD15_STAGE2_CONFIG, x, torch.tensor(g["t"]), s["ctx"])
