@@ -151,6 +151,10 @@ int rcdm_set_igemm_variant(int32_t variant);  /* 6 / 7 / 8: ping-pong kernel at 
 int rcdm_set_igemm_pingpong(int32_t on);
 /* debug: when non-NULL, every igemm block writes 4 int64 {start, end (s_memtime ticks), ticks spent in epilogues,
  * k-steps done} at trace[(blockIdx.y*gridDim.x + blockIdx.x)*4]; NULL (default) disables it. */
+/* The launch geometry the library chooses for a shape (what rcdm_gemm / rcdm_gemm_lnx / rcdm_conv3x3* will do; diagnostics:
+ * tools/ceiling.py prices tile quantisation with it): out8 = {tile variant, BM, BN, row tiles, column tiles, split-K factor,
+ * resident blocks per CU of that tile, k-steps of 64}.  No launch, no device access. */
+int rcdm_gemm_plan_query(const rcdm_gemm_desc* d, int32_t producer, int32_t consumer, int32_t* out8);
 int rcdm_debug_set_igemm_trace(void* device_buffer);
 /* debug, builds with -DRCDM_ATTN_TRACE only (tools/trace_attn.py): when non-NULL every wave of rcdm_flash_attn writes 8 int64 at
  * trace[(block * waves + wave) * 8]: {loop ticks, ticks at the barrier + K/V staging, in the QK^T issue, in the softmax, in the PV
@@ -195,6 +199,7 @@ typedef struct {
 } rcdm_conv3x3_desc;
 
 size_t rcdm_conv3x3_workspace_bytes(const rcdm_conv3x3_desc* d);
+int rcdm_conv3x3_plan_query(const rcdm_conv3x3_desc* d, int32_t* out8);   /* as rcdm_gemm_plan_query */
 int rcdm_conv3x3_up2_supported(const rcdm_conv3x3_desc* d);   /* 1 | 0, d->upsample == 2 */
 int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, const float* bias,
                  const float* rowvec, const void* residual, void* out, void* workspace,

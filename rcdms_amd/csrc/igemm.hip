@@ -1649,6 +1649,41 @@ int rcdm_conv3x3(const rcdm_conv3x3_desc* d, const void* in, const void* W, cons
   return conv_launch(d, nullptr, in, nullptr, W, bias, rowvec, residual, out, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
+// Launch geometry the library chooses for a shape (diagnostics: tools/ceiling.py prices tile quantisation with it): out[8] =
+// {tile variant, BM, BN, row tiles, column tiles, split-K factor, resident blocks per CU of that tile, k-steps of 64}.
+static void plan_out(const IgemmArgs& a, int variant, int32_t* out) {
+  out[0] = variant; out[1] = kTiles[variant].bm; out[2] = kTiles[variant].bn; out[3] = a.tilesM; out[4] = a.tilesN;
+  out[5] = a.splits; out[6] = kTiles[variant].blocks_per_cu; out[7] = a.nk;
+}
+
+int rcdm_gemm_plan_query(const rcdm_gemm_desc* d, int32_t producer, int32_t consumer, int32_t* out8) {
+  if (!d || !out8 || d->M <= 0 || d->N <= 0 || d->K <= 0) return RCDM_EINVAL;
+  IgemmArgs a{};
+  from_gemm(d, a);
+  if (producer) a.stat_out = (float*)16;
+  if (consumer) a.lnx_stat = (const float*)16;
+  int variant = 0;
+  fill_common(a, d->split_k, &variant);
+  plan_out(a, variant, out8);
+  return RCDM_OK;
+}
+
+int rcdm_conv3x3_plan_query(const rcdm_conv3x3_desc* d, int32_t* out8) {
+  if (!d || !out8) return RCDM_EINVAL;
+  IgemmArgs a{};
+  if (d->upsample == 2) {
+    const int shape = plan_up2(d, a);
+    if (shape < 0) return RCDM_ESHAPE;
+    plan_out(a, kFirstPP + shape, out8);
+    return RCDM_OK;
+  }
+  if (from_conv(d, a) || a.Cin <= 0 || a.N <= 0) return RCDM_EINVAL;
+  int variant = 0;
+  fill_common(a, d->split_k, &variant);
+  plan_out(a, variant, out8);
+  return RCDM_OK;
+}
+
 int rcdm_conv3x3_add1x1(const rcdm_conv3x3_desc* d, const void* in, const void* in2, const void* W, const float* bias,
                         const float* rowvec, const void* residual, void* out, void* workspace, size_t workspace_bytes,
                         void* stream) {

@@ -110,6 +110,7 @@ def emit_gemm(plan, A, Wt, N, K, out, bias=None, rowvec=None, residual=None, geg
              + (" gnstat" if hand is not None else ""))
     plan.keep += [Wt, bias, rv_t, x, lnx[1] if lnx else None]
     plan.op_weights[len(plan.ops) - 1] = Wt
+    plan.op_desc[len(plan.ops) - 1] = ("gemm", d, handle is not None, lnx is not None)
     if lnx is not None:
         plan.lnx_sites.append((len(plan.ops) - 1, A, lnx[1], plan.tags[-1]))
     plan.n_launch += 2 if wsb else 1
@@ -164,6 +165,7 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
     plan.add(op, f"conv3x3 {n_img}x{H}x{W} {cin}->{cout} s={stride} up={up} epi={epi}" + (f" add1x1={x2.C}" if x2 is not None else "")
              + (" gnstat" if hand is not None else ""))
     plan.op_weights[len(plan.ops) - 1] = Wt
+    plan.op_desc[len(plan.ops) - 1] = ("conv", d)
     if hand is not None:
         plan.gn_ready = dict(n_ops=len(plan.ops), key=out.ptr_key(), M=out.M, C=cout, gn=gn)
     plan.keep += [Wt, bias, rv_t]

@@ -91,6 +91,8 @@ SYMBOLS = {
     "rcdm_gemm_stat_parts": (C.c_int, [C.POINTER(GemmDesc)]),
     "rcdm_gemm_lnx_stat_parts": (C.c_int, [C.POINTER(GemmDesc), _I]),
     "rcdm_gemm_lnx_parts_ok": (C.c_int, [C.POINTER(GemmDesc), _I, _I]),
+    "rcdm_gemm_plan_query": (C.c_int, [C.POINTER(GemmDesc), _I, _I, C.POINTER(C.c_int32)]),
+    "rcdm_conv3x3_plan_query": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     "rcdm_gemm_lnx_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc), _I, _I]),
     "rcdm_set_groupnorm_fold": (C.c_int, [_I]),
     "rcdm_gemm_lnx": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(Lnx), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -319,6 +321,21 @@ def gemm_stat_parts(desc, consumer=False):
     if consumer:
         return int(load().rcdm_gemm_lnx_stat_parts(C.byref(desc), 1))
     return int(load().rcdm_gemm_stat_parts(C.byref(desc)))
+
+
+_PLAN_FIELDS = ("variant", "bm", "bn", "tiles_m", "tiles_n", "splits", "blocks_per_cu", "k_steps")
+
+
+def gemm_plan_query(desc, producer=False, consumer=False):
+    out = (C.c_int32 * 8)()
+    _check(load().rcdm_gemm_plan_query(C.byref(desc), int(bool(producer)), int(bool(consumer)), out), "rcdm_gemm_plan_query")
+    return dict(zip(_PLAN_FIELDS, out))
+
+
+def conv3x3_plan_query(desc):
+    out = (C.c_int32 * 8)()
+    _check(load().rcdm_conv3x3_plan_query(C.byref(desc), out), "rcdm_conv3x3_plan_query")
+    return dict(zip(_PLAN_FIELDS, out))
 
 
 def gemm_lnx_parts_ok(desc, parts, consumer=False):

@@ -52,6 +52,7 @@ class Plan:
         self.keep = []  # tensors that must outlive the plan (packed weights etc.)
         self.n_launch = 0
         self.op_weights = {}   # op index -> weight tensor of a GEMM / conv op (tools/prefetch_bound.py)
+        self.op_desc = {}      # op index -> ("gemm", GemmDesc, producer, consumer) | ("conv", ConvDesc)   [tools/ceiling.py]
         self.lnx_sites = []    # deferred-LayerNorm consumers: (op index, A rows, colsum S, tag)          [numerics_report]
         self.attn_sites = []   # self-attention sites: (op index, tag, weight-norm score bound, wide flag, q rows, k rows, heads, d)
 

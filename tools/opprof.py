@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--context", choices=("dense", "reference"), default="dense",
+                    help="reference: the context-row structure of SURVEY F6 (the rank-1-context plan)")
+    ap.add_argument("--list", action="store_true", help="also print the plan's ops in launch order with their times")
     a = ap.parse_args()
     import bench
     from rcdms_amd import synth
@@ -67,13 +70,14 @@ def main():
     dev = torch.device("cuda", 0)
     model = bench.build_model(dev)
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
-    story = synth.synthetic_story(stories=1, latent_hw=(a.latent, a.latent), ctx_len=85, seed=42)
+    story = synth.synthetic_story(stories=1, latent_hw=(a.latent, a.latent), ctx_len=85, seed=42, structure=a.context)
     loop = DenoiseLoop(model, 1, 5, a.latent, a.latent, 85, 2.0, sched, 4)
     loop.load(story["latents"], story["mask"], story["masked_latents"], story["ctx"])
     loop.run(use_graph=False)
     torch.cuda.synchronize()
     plan = loop.prog.plan
     agg = collections.defaultdict(lambda: [0, 0.0])
+    seq = []
     with torch.cuda.stream(loop.prog.stream):
         for op, tag in zip(plan.ops, plan.tags):
             op()
@@ -86,6 +90,7 @@ def main():
             r = agg[tag]
             r[0] += 1
             r[1] += e0.elapsed_time(e1) / a.iters * 1e3
+            seq.append((tag, e0.elapsed_time(e1) / a.iters * 1e3))
     tot = sum(v[1] for v in agg.values())
     gf_tot = sum(n * (algorithmic_work(tag)[0] or 0.0) for tag, (n, _) in agg.items())
     print(f"total {tot / 1e3:.3f} ms over {len(plan.ops)} ops; algorithmic work of the listed contractions {gf_tot / 1e3:.3f} TFLOP per step")
@@ -96,7 +101,12 @@ def main():
         c1 = f"{gf:9.2f} {gf / avg * 1e3:8.0f}" if gf else f"{'':9s} {'':8s}"
         c2 = f"{mb:8.1f} {mb / avg:6.2f}" if mb else f"{'':8s} {'':6s}"
         print(f"{us / 1e3:8.3f} {100 * us / tot:5.1f}% {n:5d} {avg:9.1f} {c1} {c2}  {tag}")
+    if a.list:
+        print("--- launch order")
+        for i, (tag, us) in enumerate(seq):
+            print(f"{i:4d} {us:8.1f} us  {tag}")
 
 
 if __name__ == "__main__":
     main()
+
