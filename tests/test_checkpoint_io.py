@@ -78,3 +78,51 @@ def test_image_grid_and_frames():
     assert px[1, 12 + 3].tolist() == [254, 153, 153]
     with pytest.raises(AssertionError):
         CK.image_grid(frames[0], 2, 5)
+
+
+def test_story_split_reader_on_an_h5_shaped_mapping(tmp_path):
+    """The ARLDM test-split read of the driver (stage2_batchtest_rcdms_model.py:41-56,440-453,257-266) on a mapping with the
+    file's layout (h5py is not part of this image; an open h5py.File is such a mapping): encoded strips decode to BGR uint8
+    arrays exactly as cv2.imdecode(IMREAD_COLOR) returns them, captions split on '|', frames are cut 128 rows at a time."""
+    import io
+    import numpy as np
+    import pytest
+    from PIL import Image
+    from rcdms_amd.checkpoint import pick_story_frames, read_story_split
+    rng = np.random.default_rng(0)
+
+    def strip(seed):
+        rgb = np.random.default_rng(seed).integers(0, 256, size=(640, 128, 3), dtype=np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(rgb).save(buf, format="PNG")       # lossless: the decoded pixels are known exactly
+        return rgb, np.frombuffer(buf.getvalue(), dtype=np.uint8)
+
+    n = 3
+    raw = {i: [strip(10 * i + s) for s in range(n)] for i in range(5)}
+    grp = {f"image{i}": [raw[i][s][1] for s in range(n)] for i in range(5)}
+    grp["text"] = [("|".join(f"story {s} frame {j}: pororo and loopy" for j in range(5))).encode("utf-8") for s in range(n)]
+    data = read_story_split({"test": grp})
+    assert sorted(data) == ["image0", "image1", "image2", "image3", "image4", "text"]
+    assert all(len(data[k]) == n for k in data)
+    for i in range(5):
+        for s in range(n):
+            assert data[f"image{i}"][s].dtype == np.uint8 and data[f"image{i}"][s].shape == (640, 128, 3)
+            assert np.array_equal(data[f"image{i}"][s], raw[i][s][0][:, :, ::-1]), "BGR, as cv2.imdecode returns"
+    assert data["text"][1] == [f"story 1 frame {j}: pororo and loopy" for j in range(5)]
+
+    class Fixed:
+        def __init__(self, seq):
+            self.seq = list(seq)
+
+        def randint(self, a, b):
+            assert (a, b) == (0, 4)
+            return self.seq.pop(0)
+
+    fr = pick_story_frames(data, 2, rng=Fixed([0, 4, 2, 1, 3]))
+    assert [f.shape for f in fr] == [(128, 128, 3)] * 5
+    assert np.array_equal(fr[1], data["image1"][2][512:640]) and np.array_equal(fr[2], data["image2"][2][256:384])
+    grp["image3"] = grp["image3"][:2]
+    with pytest.raises(ValueError, match="image3 holds 2 stories"):
+        read_story_split({"test": grp})
+    with pytest.raises((ImportError, FileNotFoundError)):
+        read_story_split(str(tmp_path / "missing.h5"))
