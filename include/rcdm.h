@@ -273,6 +273,47 @@ int rcdm_set_groupnorm_fold(int32_t on);
  * attention.py:328-330, motion_module.py:162-166).  ldy / silu of the descriptor are ignored; workspace as above. */
 int rcdm_groupnorm_stats(const rcdm_groupnorm_desc* d, const void* x, float* stat, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* the same when the partial statistics are already in `workspace` (left there by a *_gnstat call with this descriptor, as for
+ * rcdm_groupnorm_silu_prestat): the finalize launch only.  RCDM_ESHAPE when the descriptor's norm has no three-launch form. */
+int rcdm_groupnorm_stats_prestat(const rcdm_groupnorm_desc* d, float* stat, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+/* finalize only, on partials a producer wrote in its OWN geometry: partial[samples][groups][splits][3] = (count, mean, M2)
+ * fp32 -> stat[samples][groups][2] = (mean, 1 / sqrt(var + eps)); the fixed-order combination of the three-launch form.
+ * Used behind rcdm_conv3x3_wino(gn_out, ...), whose output transform leaves one partial per (sample, group, 2x2 tile). */
+int rcdm_groupnorm_finalize(int32_t samples, int32_t groups, int32_t splits, float eps, const float* partial, float* stat,
+                            void* stream);
+
+/* conv3x3, stride 1, padding 1, as Winograd F(2x2, 3x3) (wino.hip; round 6): the same operation as rcdm_conv3x3 /
+ *   rcdm_conv3x3_add1x1 — ResnetBlock3D's conv1 / conv2 (+ conv_shortcut), resnet.py:188,205-212 — with 4/9 of the
+ *   multiply-adds, for the levels where the implicit GEMM is a chain of latencies (the 16x16 / 8x8 latents: few rows, wide
+ *   channels).  Three launches: input transform B^T d B (fp32 arithmetic on the f16 pixels, one rounding), 16 (+ 4) batched
+ *   160x160-tile GEMMs with fp32 results in the workspace, output transform A^T M A + epilogue in fp32 (one rounding).
+ *   `d` is the rcdm_conv3x3_desc of the equivalent call: stride 1, upsample 0, no pad_after_only / dup_rows, h_in and w_in
+ *   even, c_in % 64 == 0 (c_in2 % 64 == 0), epilogue bits BIAS | ROWVEC | RESIDUAL; split_k 0 = heuristic (one resident
+ *   round of the chip).  U = rcdm_pack_conv3x3_wino(w): f16 [16][c_out][c_in], position p = 4 i + j holds (G g G^T)[i][j]
+ *   formed in fp32 from the fp32 weights and rounded once.  in2 / W2 (both or neither; d->c_in2, d->lda2): the second input
+ *   of rcdm_conv3x3_add1x1 and its PLAIN f16 [c_out][c_in2] 1x1 weight (rcdm_pack_f16) — it needs no transform, its four
+ *   output-parity GEMMs ride as four more batch entries; bias = the sum of the two biases.
+ *   gn != NULL: `in` is the RAW input of a GroupNorm (+ SiLU when gn->silu) whose (mean, rstd) pairs are in gn_stat
+ *   ([samples][groups][2] fp32, rcdm_groupnorm_stats) and the input transform applies x * rstd * gamma + (beta - mean * rstd *
+ *   gamma) (+ SiLU) on the way — resnet.py:185-186 / :202 in front of conv1 / conv2 — before the zero padding; gn->C == c_in,
+ *   gn->samples * gn->rows_per_sample == n_img * h_in * w_in; ldx / ldy / eps of gn are not used here.
+ *   Numerics: the MFMA operands are f16(B^T d B) (|.| <= 4 max|d|) and f16(G g G^T): about twice the operand-rounding
+ *   noise of rcdm_conv3x3 (which multiplies the f16 pixels and f16 weights themselves); accumulation, both transforms and the
+ *   epilogue are fp32.  Results are NOT bit-identical to rcdm_conv3x3.  rcdm_conv3x3_wino_supported: 1 | 0.
+ *   gn_out != NULL: the GroupNorm that reads `out` NEXT (over exactly the rows written: gn_out->C == c_out, samples *
+ *   rows_per_sample == n_img * h_in * w_in); the output transform then also leaves its partial statistics, taken from the stored
+ *   halfs, in gn_out_partial — fp32 [samples][groups][rows_per_sample / 4][3] = (count, mean, M2), one per 2x2 tile — for
+ *   rcdm_groupnorm_finalize(samples, groups, rows_per_sample / 4, eps, ...): that norm needs no statistics pass (c_out <= 8192). */
+int rcdm_conv3x3_wino_supported(const rcdm_conv3x3_desc* d);
+size_t rcdm_conv3x3_wino_workspace_bytes(const rcdm_conv3x3_desc* d);
+int rcdm_conv3x3_wino_plan_query(const rcdm_conv3x3_desc* d, int32_t* out8);   /* as rcdm_gemm_plan_query; variant 11, column tiles x entries */
+int rcdm_pack_conv3x3_wino(const float* w, int32_t c_out, int32_t c_in, void* dst, void* stream);
+int rcdm_conv3x3_wino(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn, const float* gn_stat,
+                      const float* gn_gamma, const float* gn_beta, const void* in, const void* in2, const void* U,
+                      const void* W2, const float* bias, const float* rowvec, const void* residual, void* out,
+                      void* workspace, size_t workspace_bytes, const rcdm_groupnorm_desc* gn_out, float* gn_out_partial,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps 1e-5, torch default) with optional fused positional-encoding add

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librcdm_hip.so")
-SOURCES = ["igemm.hip", "igemm8.hip", "igemm16.hip", "rowff.hip", "norm.hip", "attn.hip", "misc.hip", "runtime.hip", "comm.hip"]
+SOURCES = ["igemm.hip", "igemm8.hip", "igemm16.hip", "wino.hip", "rowff.hip", "norm.hip", "attn.hip", "misc.hip", "runtime.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar f32 adds / muls into v_pk_*_f32, which issue slower than
 # the scalars they replace next to MFMAs on gfx950 (measured +0.5 % end to end without it); the packed forms that do pay

@@ -739,6 +739,31 @@ int rcdm_groupnorm_stats(const rcdm_groupnorm_desc* d, const void* x, float* sta
   return rcdm_check_launch();
 }
 
+int rcdm_groupnorm_stats_prestat(const rcdm_groupnorm_desc* d, float* stat, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!d || !stat) return RCDM_EINVAL;
+  GnArgs a{};
+  int rc = gn_plan(d, a);
+  if (rc) return rc;
+  if (!rcdm_gn_three_launch(a)) return RCDM_ESHAPE;   // nobody can have left partials for a single-launch norm
+  const size_t need = (size_t)a.samples * a.splits * a.G * 3 * sizeof(float);
+  if (!workspace || workspace_bytes < need) return RCDM_EWORKSPACE;
+  a.partial = (float*)workspace;
+  a.stat = stat;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((a.samples * a.G + 3) / 4), dim3(256), 0, (hipStream_t)stream_, a);
+  return rcdm_check_launch();
+}
+
+int rcdm_groupnorm_finalize(int32_t samples, int32_t groups, int32_t splits, float eps, const float* partial, float* stat,
+                            void* stream_) {
+  if (!partial || !stat || samples <= 0 || groups <= 0 || splits <= 0) return RCDM_EINVAL;
+  GnArgs a{};
+  a.samples = samples; a.G = groups; a.splits = splits; a.eps = eps;
+  a.partial = const_cast<float*>(partial);
+  a.stat = stat;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((samples * groups + 3) / 4), dim3(256), 0, (hipStream_t)stream_, a);
+  return rcdm_check_launch();
+}
+
 int rcdm_layernorm(const rcdm_layernorm_desc* d, const void* x, const float* gamma, const float* beta, const float* pe,
                    void* y, void* stream_) {
   if (!d || !x || !gamma || !beta || !y) return RCDM_EINVAL;

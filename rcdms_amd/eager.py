@@ -4,7 +4,7 @@ Down/Upsample3D, InflatedConv3d, InflatedGroupNorm): pack, plan, run eagerly on 
 import torch
 
 from . import hip
-from .emit_blocks import emit_basic_block, emit_ctx_kv, emit_motion, emit_resnet, emit_transformer
+from .emit_blocks import emit_basic_block, emit_ctx_kv, emit_motion, emit_resnet, emit_transformer, wino_level
 from .emit_ops import emit_conv3x3, emit_flash_attn, emit_gemm, emit_groupnorm
 from .packer import Packer, pack_attention, pack_basic_block, pack_motion, pack_resnet, pack_transformer
 from .plan import Geo, Plan, Rows
@@ -123,7 +123,8 @@ def run_block(kind, sd, x, device=None, **kw):
     xr = _as_rows(xr_t, geo.M, c, xr_t.shape[1])
     groups = kw.get("groups", 32)
     if kind == "resnet":
-        w = pack_resnet(pk, "")
+        shp = sd["conv1.weight"].shape
+        w = pack_resnet(pk, "", wino=wino_level(geo, shp[1], shp[0]))
         temb = kw["temb"].detach().to(device, torch.float32)
         tp_w = pk.mat_f16("time_emb_proj.weight")
         tp_b = pk.vec("time_emb_proj.bias")

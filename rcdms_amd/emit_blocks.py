@@ -7,8 +7,8 @@ import torch
 
 from . import hip
 from . import switches as SW
-from .emit_ops import (XATTN_MAX_KEYS, assert_no_pending_gn, emit_conv3x3, emit_flash_attn, emit_gemm, emit_groupnorm, emit_groupnorm_stats,
-                       emit_layernorm, emit_temporal_attn, emit_xattn, emit_xattn_pack, gemm_lnx_ok)
+from .emit_ops import (XATTN_MAX_KEYS, assert_no_pending_gn, conv3x3_wino_ok, emit_conv3x3, emit_conv3x3_wino, emit_flash_attn, emit_gemm,
+                       emit_groupnorm, emit_groupnorm_stats, emit_layernorm, emit_temporal_attn, emit_xattn, emit_xattn_pack, gemm_lnx_ok)
 from .packer import MSUB_SCORE_LIMIT, attn_score_bound
 from .plan import Rows, _NS
 
@@ -19,6 +19,23 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
     out_gn = (samples, rows_per_sample, groups) of the GroupNorm that reads `out` as the very next op (the norm in front of
     the transformer / motion module / ResNet block behind this one), or None: a split-K conv2 then leaves its statistics."""
     g = geo
+    if getattr(w, "wino1", None) is not None:
+        # Winograd F(2x2, 3x3) form of both convolutions (wino_level): the norms are statistics-only launches, their apply + SiLU
+        # rides in the input transforms; conv_shortcut(x) as four parity GEMMs of conv2's batched launch
+        assert not dup_rows and x.C == w.cin
+        rv = (temb[0], temb[1], temb[2], g.f * g.hw)
+        gn1 = emit_groupnorm_stats(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, groups)
+        h1 = plan.rows("res_h1", g.M, w.cout)
+        emit_conv3x3_wino(plan, x, g.n_img, g.H, g.W, w.wino1, w.cin, w.cout, h1, bias=w.cb1, rowvec=rv, gn=gn1,
+                          gn_out=(g.b, g.f * g.hw, groups))
+        gn2 = emit_groupnorm_stats(plan, h1, g.b, g.f * g.hw, w.g2, w.b2, eps, groups)
+        if w.shortcut is not None:
+            emit_conv3x3_wino(plan, h1, g.n_img, g.H, g.W, w.wino2, w.cout, w.cout, out, bias=w.cb2sc, scale=out_scale, gn=gn2,
+                              x2=x, W2=w.shortcut)
+        else:
+            emit_conv3x3_wino(plan, h1, g.n_img, g.H, g.W, w.wino2, w.cout, w.cout, out, bias=w.cb2, residual=x, scale=out_scale,
+                              gn=gn2)
+        return
     a1 = plan.rows("norm", g.M, x.C)
     emit_groupnorm(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, True, a1, groups)   # (first: x may carry a producer's statistics)
     res = x
@@ -38,6 +55,17 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
         return
     emit_conv3x3(plan, a2, g.n_img, g.H, g.W, w.conv2, w.cout, w.cout, out, bias=w.cb2, residual=res, scale=out_scale,
                  dup_rows=dup_rows, gn=out_gn)
+
+
+WINO_MIN_CHANNELS = 640   # k-loops of >= 10 steps per position GEMM; narrower convs keep the nine-tap form at every size
+
+
+def wino_level(geo, cin, cout):
+    """Whether the ResNet blocks of this geometry take the Winograd form of their 3x3 convolutions (switches.WINO: the latent
+    sides it is used at — where the nine-tap implicit GEMM is a split-K latency chain, not a stream)."""
+    return (geo.H == geo.W and geo.H in SW.WINO and min(cin, cout) >= WINO_MIN_CHANNELS and
+            conv3x3_wino_ok(geo.n_img, geo.H, geo.W, cin, cout) and
+            conv3x3_wino_ok(geo.n_img, geo.H, geo.W, cout, cout, cin if cin != cout else 0))
 
 
 # a chain launch (rcdm_rowchain / rcdm_ff_fused, rowff.hip) is one block of 160 rows per CU: below ~3/4 of a chip's worth of

@@ -187,7 +187,8 @@ def emit_groupnorm(plan, x, samples, rows_per_sample, gamma, beta, eps, silu, ou
     rdy = getattr(plan, "gn_ready", None)
     plan.gn_ready = None
     pre = (rdy is not None and rdy["n_ops"] == len(plan.ops) and rdy["key"] == x.ptr_key() and rdy["M"] == x.M and
-           rdy["C"] == x.C and rdy["gn"] == (samples, rows_per_sample, groups) and hip.groupnorm_prestat_ok(d))
+           rdy["C"] == x.C and rdy["gn"] == (samples, rows_per_sample, groups) and rdy.get("tiles") is None and
+           hip.groupnorm_prestat_ok(d))
     assert rdy is None or rdy["n_ops"] != len(plan.ops) or pre, "a producer left GroupNorm statistics that nobody consumes"
 
     def op():
@@ -201,19 +202,85 @@ def emit_groupnorm(plan, x, samples, rows_per_sample, gamma, beta, eps, silu, ou
 
 
 def emit_groupnorm_stats(plan, x, samples, rows_per_sample, gamma, beta, eps, groups=32):
-    """(mean, rstd) of a GroupNorm only — the consumer (emit_rowchain's `gn`) applies it while loading its rows.
-    Returns the `gn` tuple emit_rowchain takes."""
+    """(mean, rstd) of a GroupNorm only — the consumer (emit_rowchain's `gn`, emit_conv3x3_wino's `gn`) applies it while loading
+    its rows.  Returns the `gn` tuple they take.  Where the producer of x left this norm's partial statistics (plan.gn_ready,
+    _gn_handoff) only the finalize launch is emitted."""
     d = hip.GroupNormDesc(samples, rows_per_sample, x.C, groups, x.ld, x.ld, eps, 0)
     ws = plan.scratch("gn_ws", hip.groupnorm_workspace_bytes(d))
     stat = plan.scratch("gn_stat", samples * groups * 2 * 4)
-    assert_no_pending_gn(plan, "a statistics-only GroupNorm launch")
+    rdy = getattr(plan, "gn_ready", None)
+    plan.gn_ready = None
+    match = (rdy is not None and rdy["n_ops"] == len(plan.ops) and rdy["key"] == x.ptr_key() and rdy["M"] == x.M and
+             rdy["C"] == x.C and rdy["gn"] == (samples, rows_per_sample, groups))
+    tiles = match and rdy.get("tiles") is not None     # per-tile partials of a Winograd conv's output transform (its own geometry)
+    pre = match and (tiles or hip.groupnorm_prestat_ok(d))
+    assert rdy is None or rdy["n_ops"] != len(plan.ops) or pre, "a producer left GroupNorm statistics that nobody consumes"
 
     def op():
-        hip.groupnorm_stats(d, x.ptr, stat.ptr, ws.ptr, ws.nbytes)
-    plan.add(op, f"groupnorm_stats S={samples} R={rows_per_sample} C={x.C}")
+        if tiles:
+            hip.groupnorm_finalize(samples, groups, rdy["tiles"][1], eps, rdy["tiles"][0].ptr, stat.ptr)
+        elif pre:
+            hip.groupnorm_stats_prestat(d, stat.ptr, ws.ptr, ws.nbytes)
+        else:
+            hip.groupnorm_stats(d, x.ptr, stat.ptr, ws.ptr, ws.nbytes)
+    plan.add(op, f"groupnorm_stats S={samples} R={rows_per_sample} C={x.C}" + (" prestat" if pre else ""))
     plan.keep += [gamma, beta]
-    plan.n_launch += 2
+    plan.n_launch += 1 if pre else 2
     return (stat, gamma, beta, groups, rows_per_sample)
+
+
+def conv3x3_wino_ok(n_img, H, W, cin, cout, cin2=0):
+    """Whether rcdm_conv3x3_wino takes a stride-1 conv of this geometry (even image sides, whole 64-channel k-steps)."""
+    d = hip.ConvDesc(n_img, H, W, cin, cout, 1, 0, cin, cout, 0, 0, 1, 0, 1.0, 0, 0, 0, cin2, cin2)
+    return hip.conv3x3_wino_supported(d)
+
+
+def emit_conv3x3_wino(plan, x, n_img, H, W, U, cin, cout, out, bias=None, rowvec=None, residual=None, scale=1.0, split_k=0,
+                      gn=None, silu=True, x2=None, W2=None, gn_out=None):
+    """Stride-1 conv3x3 in the Winograd F(2x2, 3x3) form (rcdm_conv3x3_wino; ResnetBlock3D conv1 / conv2, resnet.py:188,205-212).
+    gn = emit_groupnorm_stats(...) of the norm in front of the conv: x holds its RAW input and the input transform applies the
+    normalisation (+ SiLU) on the way.  x2 / W2: the second input and its plain f16 [cout][x2.C] 1x1 weight (conv_shortcut).
+    gn_out = (samples, rows_per_sample, groups) of the GroupNorm whose STATISTICS-ONLY launch (emit_groupnorm_stats) is the very
+    next op on `out`: the output transform leaves per-tile partials and that launch becomes the finalize alone."""
+    epi = 0
+    if bias is not None:
+        epi |= hip.EPI_BIAS
+    if rowvec is not None:
+        epi |= hip.EPI_ROWVEC
+    if residual is not None:
+        epi |= hip.EPI_RESIDUAL
+    d = hip.ConvDesc(n_img, H, W, cin, cout, 1, 0, x.ld, out.ld, residual.ld if residual is not None else 0, epi,
+                     rowvec[3] if rowvec else 1, rowvec[2] if rowvec else 0, scale, split_k, 0, 0,
+                     x2.C if x2 is not None else 0, x2.ld if x2 is not None else 0)
+    assert hip.conv3x3_wino_supported(d) and (x2 is None) == (W2 is None)
+    ws = plan.scratch("wino_ws", hip.conv3x3_wino_workspace_bytes(d))
+    assert_no_pending_gn(plan, "a Winograd conv launch")
+    gnd = None
+    if gn is not None:
+        stat, gamma, beta, groups, rps = gn
+        gnd = hip.GroupNormDesc(x.M // rps, rps, cin, groups, x.ld, x.ld, 1e-5, int(silu))
+    god, gop = None, None
+    if gn_out is not None and SW.GN_PRESTAT and gn_out[0] * gn_out[1] == out.M and gn_out[1] % (H * W) == 0 and cout % gn_out[2] == 0 \
+            and cout * 8 <= 65536 and gn_out[2] <= 64:
+        god = hip.GroupNormDesc(gn_out[0], gn_out[1], cout, gn_out[2], out.ld, out.ld, 1e-5, 0)
+        gop = plan.scratch("gn_tile_part", gn_out[0] * gn_out[2] * (gn_out[1] // 4) * 3 * 4)
+    bptr = bias.data_ptr() if bias is not None else 0
+    rv_t, rv_off = (rowvec[0], rowvec[1]) if rowvec else (None, 0)
+
+    def op():
+        rvp = (rv_t.data_ptr() + 4 * rv_off) if rv_t is not None else 0
+        hip.conv3x3_wino(d, x.ptr, U.data_ptr(), bptr, rvp, residual.ptr if residual is not None else 0, out.ptr, ws.ptr, ws.nbytes,
+                         x2=x2.ptr if x2 is not None else 0, W2=W2.data_ptr() if W2 is not None else 0, gn=gnd,
+                         gn_stat=gn[0].ptr if gn is not None else 0, gn_gamma=gn[1].data_ptr() if gn is not None else 0,
+                         gn_beta=gn[2].data_ptr() if gn is not None else 0, gn_out=god, gn_out_partial=gop.ptr if gop is not None else 0)
+    plan.add(op, f"conv3x3_wino {n_img}x{H}x{W} {cin}->{cout} epi={epi}" + (f" add1x1={x2.C}" if x2 is not None else "")
+             + (" gn" if gn is not None else "") + (" gnstat" if god is not None else ""))
+    if god is not None:
+        plan.gn_ready = dict(n_ops=len(plan.ops), key=out.ptr_key(), M=out.M, C=cout, gn=tuple(gn_out), tiles=(gop, gn_out[1] // 4))
+    plan.op_weights[len(plan.ops) - 1] = U
+    plan.op_desc[len(plan.ops) - 1] = ("wino", d)
+    plan.keep += [U, W2, bias, rv_t, gnd, god]
+    plan.n_launch += 3
 
 
 def emit_layernorm(plan, x, gamma, beta, out, pe=None, rows_per_frame=1, frames=1):

@@ -111,6 +111,7 @@ SYMBOLS = {
     "rcdm_groupnorm_workspace_bytes": (_SZ, [C.POINTER(GroupNormDesc)]),
     "rcdm_groupnorm_silu": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _SZ, _P]),
+    "rcdm_groupnorm_stats_prestat": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _SZ, _P]),
     "rcdm_groupnorm_prestat_ok": (C.c_int, [C.POINTER(GroupNormDesc)]),
     "rcdm_groupnorm_silu_prestat": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _SZ, _P]),
     "rcdm_gemm_gnstat_ok": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GroupNormDesc)]),
@@ -152,6 +153,13 @@ SYMBOLS = {
     "rcdm_pack_conv3x3_up2": (C.c_int, [_P, _I, _I, _P, _P]),
     "rcdm_matmul_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "rcdm_conv3x3_up2_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rcdm_conv3x3_wino_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rcdm_conv3x3_wino_workspace_bytes": (_SZ, [C.POINTER(ConvDesc)]),
+    "rcdm_conv3x3_wino_plan_query": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
+    "rcdm_pack_conv3x3_wino": (C.c_int, [_P, _I, _I, _P, _P]),
+    "rcdm_conv3x3_wino": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
+                                    C.POINTER(GroupNormDesc), _P, _P]),
+    "rcdm_groupnorm_finalize": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P]),
     "rcdm_pack_geglu_rows": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
     "rcdm_graph_begin_capture": (C.c_int, [_P]),
     "rcdm_graph_end_capture": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
@@ -294,6 +302,11 @@ def conv3x3_add1x1_gnstat(desc, gn, x, x2, W, bias, rowvec, residual, out, ws_pt
 def groupnorm_stats(desc, x, stat, ws_ptr, ws_bytes, stream=None):
     _check(load().rcdm_groupnorm_stats(C.byref(desc), x, stat, ws_ptr, ws_bytes,
                                        stream_ptr() if stream is None else stream), "rcdm_groupnorm_stats")
+
+
+def groupnorm_stats_prestat(desc, stat, ws_ptr, ws_bytes, stream=None):
+    _check(load().rcdm_groupnorm_stats_prestat(C.byref(desc), stat, ws_ptr, ws_bytes,
+                                               stream_ptr() if stream is None else stream), "rcdm_groupnorm_stats_prestat")
 
 
 def layernorm(desc, x, gamma, beta, pe, y, stream=None):
@@ -508,6 +521,40 @@ def pack_conv3x3_up2(w, c_out, c_in, dst, stream=None):
 
 def conv3x3_up2_supported(desc):
     return bool(load().rcdm_conv3x3_up2_supported(C.byref(desc)))
+
+
+def conv3x3_wino_supported(desc):
+    return bool(load().rcdm_conv3x3_wino_supported(C.byref(desc)))
+
+
+def conv3x3_wino_workspace_bytes(desc):
+    return load().rcdm_conv3x3_wino_workspace_bytes(C.byref(desc))
+
+
+def conv3x3_wino_plan_query(desc):
+    out = (C.c_int32 * 8)()
+    _check(load().rcdm_conv3x3_wino_plan_query(C.byref(desc), out), "rcdm_conv3x3_wino_plan_query")
+    return list(out)
+
+
+def pack_conv3x3_wino(w, c_out, c_in, dst, stream=None):
+    _check(load().rcdm_pack_conv3x3_wino(w, c_out, c_in, dst, stream_ptr() if stream is None else stream),
+           "rcdm_pack_conv3x3_wino")
+
+
+def conv3x3_wino(desc, x, U, bias, rowvec, residual, out, ws_ptr, ws_bytes, x2=0, W2=0, gn=None, gn_stat=0, gn_gamma=0, gn_beta=0,
+                 gn_out=None, gn_out_partial=0, stream=None):
+    """rcdm_conv3x3_wino: gn = GroupNormDesc of the norm (+ SiLU) the input transform applies to x (None: x as it is);
+    gn_out = GroupNormDesc of the norm that reads `out` next, its per-tile partial statistics go to gn_out_partial."""
+    _check(load().rcdm_conv3x3_wino(C.byref(desc), C.byref(gn) if gn is not None else None, gn_stat, gn_gamma, gn_beta, x, x2, U, W2,
+                                    bias, rowvec, residual, out, ws_ptr, ws_bytes, C.byref(gn_out) if gn_out is not None else None,
+                                    gn_out_partial, stream_ptr() if stream is None else stream),
+           "rcdm_conv3x3_wino")
+
+
+def groupnorm_finalize(samples, groups, splits, eps, partial, stat, stream=None):
+    _check(load().rcdm_groupnorm_finalize(samples, groups, splits, eps, partial, stat, stream_ptr() if stream is None else stream),
+           "rcdm_groupnorm_finalize")
 
 
 def pack_conv3x3(w, c_out, c_in, cin_pad, dst, stream=None):

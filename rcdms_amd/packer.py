@@ -64,6 +64,15 @@ class Packer:
         self._tmp.append(src)
         return _NS(W=dst, b=(hip.matmul_f32(wpo, b2) + bpo).contiguous())
 
+    def conv3x3_wino(self, key):
+        """Winograd F(2x2, 3x3) weights of a stride-1 conv (rcdm_conv3x3_wino): f16 [16][cout][cin] = G g G^T, formed in fp32."""
+        w = self.f32(key)
+        cout, cin = w.shape[0], w.shape[1]
+        dst = torch.empty(16, cout, cin, dtype=torch.float16, device=self.device)
+        hip.pack_conv3x3_wino(w.data_ptr(), cout, cin, dst.data_ptr())
+        self._tmp.append(w)
+        return dst
+
     def conv3x3_up2(self, key):
         """Phase weights of an Upsample3D conv (rcdm_conv3x3 with upsample = 2): f16 [4][cout][4 * cin]."""
         w = self.f32(key)
@@ -174,10 +183,21 @@ class Packer:
         self._tmp.clear()
 
 
-def pack_resnet(pk, p):
+def pack_resnet(pk, p, wino=False):
+    """wino: the block's two 3x3 convolutions in the Winograd form (w.wino1 / w.wino2 instead of w.conv1 / w.conv2; the 1x1
+    conv_shortcut stays a plain f16 matrix, w.shortcut, and rides as four parity GEMMs of the same launch)."""
     w = _NS(cin=pk.sd[p + "conv1.weight"].shape[1], cout=pk.sd[p + "conv1.weight"].shape[0])
     w.g1, w.b1 = pk.vec(p + "norm1.weight"), pk.vec(p + "norm1.bias")
     w.g2, w.b2 = pk.vec(p + "norm2.weight"), pk.vec(p + "norm2.bias")
+    w.wino1 = None
+    if wino and w.cin % 64 == 0 and w.cout % 64 == 0:
+        w.wino1, w.cb1 = pk.conv3x3_wino(p + "conv1.weight"), pk.vec(p + "conv1.bias")
+        w.wino2, w.cb2 = pk.conv3x3_wino(p + "conv2.weight"), pk.vec(p + "conv2.bias")
+        w.conv1 = w.conv2 = w.shortcut = w.conv2sc = None
+        if pk.has(p + "conv_shortcut.weight"):
+            w.shortcut, w.sb = pk.mat_f16(p + "conv_shortcut.weight"), pk.vec(p + "conv_shortcut.bias")
+            w.cb2sc = (w.cb2 + w.sb).contiguous()
+        return w
     w.conv1, w.cb1 = pk.conv3x3(p + "conv1.weight"), pk.vec(p + "conv1.bias")
     w.conv2, w.cb2 = pk.conv3x3(p + "conv2.weight"), pk.vec(p + "conv2.bias")
     w.shortcut = w.conv2sc = None

@@ -6,7 +6,7 @@ the reference recomputes them every step, attention.py:139-141), graph capture a
 import torch
 
 from . import hip
-from .emit_blocks import (CHAIN_MIN_ROWS, emit_ctx_kv, emit_motion, emit_rank1_ctx, emit_resnet, emit_transformer,
+from .emit_blocks import (CHAIN_MIN_ROWS, emit_ctx_kv, emit_motion, emit_rank1_ctx, emit_resnet, emit_transformer, wino_level,
                           full_rank_runs)
 from .emit_ops import XATTN_MAX_KEYS, emit_conv3x3, emit_groupnorm, emit_upsample_conv
 from .packer import Packer, pack_motion, pack_resnet, pack_transformer
@@ -105,6 +105,10 @@ class UNetProgram:
         def temb_of(p):
             return (tproj, tp_off[p], tp_total)
 
+        def resnet_w(p, geo):
+            shp = sd[p + "conv1.weight"].shape
+            return pack_resnet(pk, p, wino=wino_level(geo, shp[1], shp[0]))
+
         # ---- skip/concat layout: simulate the up path to learn each concat buffer's width ----------
         skip_specs = [(boc[0], 0)]
         for i in range(nlev):
@@ -199,7 +203,7 @@ class UNetProgram:
                         emit_resnet(plan, pack_resnet(pk, pr), cur.rows(0, g0h.M), g0h, temb_of(pr), dst.rows(0, g0h.M),
                                     eps, groups, dup_rows=g0h.M)
                     else:
-                        emit_resnet(plan, pack_resnet(pk, pr), cur, geo, temb_of(pr), dst, eps, groups, out_gn=nxt)
+                        emit_resnet(plan, resnet_w(pr, geo), cur, geo, temb_of(pr), dst, eps, groups, out_gn=nxt)
                 elif st == "t":
                     transformer(pb + f"attentions.{j}.", cur, geo, dst, shared_half=shared, out_gn=nxt)
                 else:
@@ -231,7 +235,7 @@ class UNetProgram:
         small_mid = gm.M < CHAIN_MIN_ROWS
         mid_motion = bool(cfg["use_motion_module"] and cfg["motion_module_mid_block"])
         per_frame, cross_frame = (gm.n_img, gm.hw, groups), (gm.b, gm.f * gm.hw, groups)
-        emit_resnet(plan, pack_resnet(pk, "mid_block.resnets.0."), cur, gm, temb_of("mid_block.resnets.0."), m0,
+        emit_resnet(plan, resnet_w("mid_block.resnets.0.", gm), cur, gm, temb_of("mid_block.resnets.0."), m0,
                     eps, groups, 1.0 / cfg.get("mid_block_scale_factor", 1), out_gn=per_frame if small_mid else None)
         m1 = plan.rows("blk1", gm.M, boc[-1])
         transformer("mid_block.attentions.0.", m0, gm, m1,
@@ -242,7 +246,7 @@ class UNetProgram:
             motion("mid_block.motion_modules.0.", m1, gm, m2, out_gn=cross_frame if small_mid else None)
             cur = m2
         k = n_skip - 1
-        emit_resnet(plan, pack_resnet(pk, "mid_block.resnets.1."), cur, gm, temb_of("mid_block.resnets.1."),
+        emit_resnet(plan, resnet_w("mid_block.resnets.1.", gm), cur, gm, temb_of("mid_block.resnets.1."),
                     h_view(k), eps, groups, 1.0 / cfg.get("mid_block_scale_factor", 1))
 
         # ---- up path ---------------------------------------------------------------------------------

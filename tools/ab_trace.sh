@@ -8,7 +8,7 @@ VAR=$1; A=$2; B=$3
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 for v in "$A" "$B"; do
   out=gpurun_out/abt_${VAR}_$v; mkdir -p "$out"
-  env $VAR=$v timeout 400 rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- python bench.py --steps 1 --warmup 0 --ddim-steps 4 --no-cpu-baseline > "$out/trace.log" 2>&1
+  env $VAR=$v timeout 400 rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- python bench.py --steps 1 --warmup 0 --ddim-steps 4 --no-cpu-baseline --no-extra-configs > "$out/trace.log" 2>&1
   python tools/prof_summary.py "$out/trace" 5 < /dev/null > "$out/kernel_stats.txt"
   rm -rf "$out/trace"
 done
