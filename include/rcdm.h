@@ -309,6 +309,10 @@ int rcdm_conv3x3_wino_supported(const rcdm_conv3x3_desc* d);
 size_t rcdm_conv3x3_wino_workspace_bytes(const rcdm_conv3x3_desc* d);
 int rcdm_conv3x3_wino_plan_query(const rcdm_conv3x3_desc* d, int32_t* out8);   /* as rcdm_gemm_plan_query; variant 11, column tiles x entries */
 int rcdm_pack_conv3x3_wino(const float* w, int32_t c_out, int32_t c_in, void* dst, void* stream);
+/* tuning / test switch: 1 = the batched GEMM of rcdm_conv3x3_wino leaves f16 slabs (half the bytes between it and the output
+ * transform, whole-row stores; every transform-domain sum is rounded to f16 before A^T M A), 0 = fp32 slabs, -1 = default
+ * (environment RCDM_WINO_SLAB16, else 1). */
+int rcdm_set_wino_slab_f16(int32_t on);
 int rcdm_conv3x3_wino(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn, const float* gn_stat,
                       const float* gn_gamma, const float* gn_beta, const void* in, const void* in2, const void* U,
                       const void* W2, const float* bias, const float* rowvec, const void* residual, void* out,

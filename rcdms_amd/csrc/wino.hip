@@ -20,6 +20,8 @@
 #include "common.h"
 #include "igemm_args.h"
 #include "pp_sync.h"
+#include "igemm_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,7 +36,8 @@ struct WinoArgs {
   const f16* res;
   f16* out;
   f16* V;            // workspace: f16 [16][T][K]
-  float* slab;       // workspace: fp32 [E][splits][T][N]
+  float* slab;       // workspace: fp32 (or, slab16 != 0, f16) [E][splits][T][N]
+  int slab16;
   int n_img, H, W, th, tw, T, N, K, K2;
   int lda, lda2, ldc, ldr, ldt, rows_per_sample;
   int epi;
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const WinoArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // (2) the batched GEMM: igemm16.hip's loop (160x160 tile, 4 waves, two blocks per CU, one barrier per 64-deep k-step, 2-stage
 // LDS-DMA ring, XOR swizzle on the source side), entry and split-K slice from blockIdx.y, fp32 tile to the entry's slab.
+template <bool S16>   // S16: the tile goes to an f16 slab through the staged, coalesced epilogue of igemm_epilogue.h
 __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs p) {
   constexpr int BM = 160, BN = 160, FM = 5, FN = 5;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs p) {
   const int ks_begin = split * nkps;
   const int nkl = min(nk, ks_begin + nkps) - ks_begin;
   const int Kd = extra ? p.K2 : p.K;             // contraction width = W row length
-  float* const dst = p.slab + ((size_t)entry * p.splits + split) * p.T * p.N;
+  const size_t slab_off = ((size_t)entry * p.splits + split) * p.T * p.N;
 
   int cm0, cn0;
   {
@@ -253,15 +257,26 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs p) {
       __builtin_amdgcn_s_setprio(3);
     }
   }
-  // fp32 tile to the slab: 16 B per lane, 64-byte runs per tile row (an empty slice — more splits than k-steps — writes zeros)
   const int row0 = wm * (BM / 2), col0 = wn * (BN / 2);
+  if constexpr (S16) {
+    // f16 slab: accumulators -> f16 tile in LDS -> whole-row 16-byte stores (the plain-projection path of tile_epilogue)
+    wait_lgkm0();
+    tick_barrier();   // every wave is done reading the ring
+    IgemmArgs q{};
+    q.out = (f16*)p.slab + slab_off;
+    q.M = p.T; q.N = p.N; q.ldc = p.N; q.epi = 0; q.out_scale = 1.0f; q.dup = 0;
+    tile_epilogue<FM, FN, false, 256, BM, BN, false, false>(q, smem, acc, cm0, cn0, row0, col0, l15, kg, t, nullptr);
+  } else {
+    // fp32 tile to the slab: 16 B per lane, 64-byte runs per tile row (an empty slice — more splits than k-steps — writes zeros)
+    float* const dst = p.slab + slab_off;
 #pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = cm0 + row0 + j * 16 + l15;
+    for (int j = 0; j < FM; ++j) {
+      const int m = cm0 + row0 + j * 16 + l15;
 #pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      const int n = cn0 + col0 + i * 16 + 4 * kg;
-      if (m < p.T && n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
+      for (int i = 0; i < FN; ++i) {
+        const int n = cn0 + col0 + i * 16 + 4 * kg;
+        if (m < p.T && n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
+      }
     }
   }
 }
@@ -273,7 +288,18 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs p) {
 // go_partial: the block also leaves the tile's partial statistics for the GroupNorm that reads `out` next — taken from the
 // STORED halfs (what a statistics pass would read back), per-channel sums through LDS, then one thread per group in channel
 // order: deterministic.
-template <int SP>
+template <bool S16>
+__device__ __forceinline__ f32x4 slab_load4(const WinoArgs& p, size_t off) {
+  if constexpr (S16) {
+    union { uint2 u; f16 e[4]; } h;
+    h.u = *(const uint2*)((const f16*)p.slab + off);
+    return f32x4{(float)h.e[0], (float)h.e[1], (float)h.e[2], (float)h.e[3]};
+  } else {
+    return *(const f32x4*)(p.slab + off);
+  }
+}
+
+template <int SP, bool S16>
 __global__ __launch_bounds__(512) void wino_out_kernel(const WinoArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nch = p.N >> 2;
@@ -288,7 +314,7 @@ __global__ __launch_bounds__(512) void wino_out_kernel(const WinoArgs p) {
   union H4 { uint2 u; f16 e[4]; };
   for (int cg4 = threadIdx.x; cg4 < nch; cg4 += blockDim.x) {
     const int n = cg4 * 4;
-    const float* src = p.slab + (size_t)t * p.N + n;
+    const size_t src = (size_t)t * p.N + n;
     // the residual rows are requested first (the coldest operand of the thread)
     H4 rr[4];
 #pragma unroll
@@ -298,18 +324,18 @@ __global__ __launch_bounds__(512) void wino_out_kernel(const WinoArgs p) {
     }
     f32x4 m[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) m[e] = *(const f32x4*)(src + e * eplane);
+    for (int e = 0; e < 16; ++e) m[e] = slab_load4<S16>(p, src + e * eplane);
     if constexpr (SP == 2) {
       f32x4 m2[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) m2[e] = *(const f32x4*)(src + e * eplane + splane);
+      for (int e = 0; e < 16; ++e) m2[e] = slab_load4<S16>(p, src + e * eplane + splane);
 #pragma unroll
       for (int e = 0; e < 16; ++e) m[e] += m2[e];
     } else if constexpr (SP == 0) {
       for (int s = 1; s < p.splits; ++s) {
         f32x4 m2[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) m2[e] = *(const f32x4*)(src + e * eplane + s * splane);
+        for (int e = 0; e < 16; ++e) m2[e] = slab_load4<S16>(p, src + e * eplane + s * splane);
 #pragma unroll
         for (int e = 0; e < 16; ++e) m[e] += m2[e];
       }
@@ -330,10 +356,10 @@ __global__ __launch_bounds__(512) void wino_out_kernel(const WinoArgs p) {
     if (p.E > 16) {
       f32x4 x[4];
 #pragma unroll
-      for (int ab = 0; ab < 4; ++ab) x[ab] = *(const f32x4*)(src + (16 + ab) * eplane);
+      for (int ab = 0; ab < 4; ++ab) x[ab] = slab_load4<S16>(p, src + (16 + ab) * eplane);
       for (int s = 1; s < p.splits; ++s) {
 #pragma unroll
-        for (int ab = 0; ab < 4; ++ab) x[ab] += *(const f32x4*)(src + (16 + ab) * eplane + s * splane);
+        for (int ab = 0; ab < 4; ++ab) x[ab] += slab_load4<S16>(p, src + (16 + ab) * eplane + s * splane);
       }
 #pragma unroll
       for (int ab = 0; ab < 4; ++ab) o[ab] += x[ab];
@@ -453,11 +479,12 @@ int wino_plan(const rcdm_conv3x3_desc* d, WinoArgs& a) {
   if ((size_t)d->n_img * d->h_in * d->w_in * d->lda * 2 >= (1ull << 31)) return RCDM_ESHAPE;
   if (d->c_in2 && (size_t)d->n_img * d->h_in * d->w_in * d->lda2 * 2 >= (1ull << 31)) return RCDM_ESHAPE;
   if ((size_t)a.N * (a.K > a.K2 ? a.K : a.K2) * 2 >= (1ull << 31)) return RCDM_ESHAPE;
-  // split-K: fill one resident round of the chip (two blocks per CU), a slice keeps >= 5 k-steps
+  // split-K: up to one block per CU (measured at the 8x8 level, 128 tile-entries: split 2 beats 1 and 4 — the slabs of every
+  // extra slice are read back by the output transform), a slice keeps >= 5 k-steps
   int splits = d->split_k;
   if (splits <= 0) {
     const int blocks = a.E * a.tilesM * a.tilesN;
-    splits = (2 * wino_cus()) / (blocks > 0 ? blocks : 1);
+    splits = wino_cus() / (blocks > 0 ? blocks : 1);
     if (splits > a.nk / 5) splits = a.nk / 5;
     if (splits > 8) splits = 8;
   }
@@ -469,7 +496,18 @@ int wino_plan(const rcdm_conv3x3_desc* d, WinoArgs& a) {
   return RCDM_OK;
 }
 size_t wino_v_bytes(const WinoArgs& a) { return align256((size_t)16 * a.T * a.K * 2); }
-size_t wino_slab_bytes(const WinoArgs& a) { return align256((size_t)a.E * a.splits * a.T * a.N * 4); }
+size_t wino_slab_bytes(const WinoArgs& a) { return align256((size_t)a.E * a.splits * a.T * a.N * 4); }   // (sized for fp32 in either mode)
+
+// 1: the batched GEMM writes f16 slabs (half the slab traffic, coalesced stores; every transform-domain value rounded to f16
+// before the output transform), 0: fp32 slabs.  -1 = not set: environment RCDM_WINO_SLAB16, default 1 (measured: -10 us per 16x16-level conv, whole-UNet rel-RMS +0.2 ... +2.7 %).
+int g_wino_slab16 = -1;
+int wino_slab16() {
+  if (g_wino_slab16 < 0) {
+    const char* e = getenv("RCDM_WINO_SLAB16");
+    g_wino_slab16 = e ? (atoi(e) != 0) : 1;
+  }
+  return g_wino_slab16;
+}
 
 }  // namespace
 
@@ -492,6 +530,11 @@ int rcdm_conv3x3_wino_plan_query(const rcdm_conv3x3_desc* d, int32_t* out8) {
   if (rc != RCDM_OK || !out8) return rc != RCDM_OK ? rc : RCDM_EINVAL;
   out8[0] = 11; out8[1] = 160; out8[2] = 160; out8[3] = a.tilesM; out8[4] = a.tilesN * a.E; out8[5] = a.splits; out8[6] = 2;
   out8[7] = a.nk;
+  return RCDM_OK;
+}
+
+int rcdm_set_wino_slab_f16(int32_t on) {
+  g_wino_slab16 = on < 0 ? -1 : (on ? 1 : 0);
   return RCDM_OK;
 }
 
@@ -540,6 +583,7 @@ int rcdm_conv3x3_wino(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn,
   a.in = (const f16*)in; a.in2 = (const f16*)in2; a.U = (const f16*)U; a.W2 = (const f16*)W2;
   a.bias = bias; a.rowvec = rowvec; a.res = (const f16*)residual; a.out = (f16*)out;
   a.V = (f16*)workspace;
+  a.slab16 = wino_slab16();
   a.slab = (float*)((char*)workspace + wino_v_bytes(a));
   hipStream_t stream = (hipStream_t)stream_;
   {
@@ -549,18 +593,27 @@ int rcdm_conv3x3_wino(const rcdm_conv3x3_desc* d, const rcdm_groupnorm_desc* gn,
   {
     constexpr int kLds = 2 * (160 + 160) * 128;
     static bool attr_set[64] = {};
-    if (rcdm_first_on_device(attr_set))
-      (void)hipFuncSetAttribute((const void*)wino_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    hipLaunchKernelGGL(wino_gemm_kernel, dim3(a.tilesM * a.tilesN, a.E * a.splits), dim3(256), kLds, stream, a);
+    if (rcdm_first_on_device(attr_set)) {
+      (void)hipFuncSetAttribute((const void*)wino_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      (void)hipFuncSetAttribute((const void*)wino_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    }
+    if (a.slab16) hipLaunchKernelGGL(wino_gemm_kernel<true>, dim3(a.tilesM * a.tilesN, a.E * a.splits), dim3(256), kLds, stream, a);
+    else hipLaunchKernelGGL(wino_gemm_kernel<false>, dim3(a.tilesM * a.tilesN, a.E * a.splits), dim3(256), kLds, stream, a);
   }
   {
     int threads = ((a.N >> 2) + 63) / 64 * 64;
     if (threads > 512) threads = 512;
     const size_t lds = a.go_partial ? (size_t)a.N * 8 : 0;
     const dim3 grid((unsigned)a.T);
-    if (a.splits == 1) hipLaunchKernelGGL(wino_out_kernel<1>, grid, dim3(threads), lds, stream, a);
-    else if (a.splits == 2) hipLaunchKernelGGL(wino_out_kernel<2>, grid, dim3(threads), lds, stream, a);
-    else hipLaunchKernelGGL(wino_out_kernel<0>, grid, dim3(threads), lds, stream, a);
+    if (a.slab16) {
+      if (a.splits == 1) hipLaunchKernelGGL((wino_out_kernel<1, true>), grid, dim3(threads), lds, stream, a);
+      else if (a.splits == 2) hipLaunchKernelGGL((wino_out_kernel<2, true>), grid, dim3(threads), lds, stream, a);
+      else hipLaunchKernelGGL((wino_out_kernel<0, true>), grid, dim3(threads), lds, stream, a);
+    } else {
+      if (a.splits == 1) hipLaunchKernelGGL((wino_out_kernel<1, false>), grid, dim3(threads), lds, stream, a);
+      else if (a.splits == 2) hipLaunchKernelGGL((wino_out_kernel<2, false>), grid, dim3(threads), lds, stream, a);
+      else hipLaunchKernelGGL((wino_out_kernel<0, false>), grid, dim3(threads), lds, stream, a);
+    }
   }
   return rcdm_check_launch();
 }

@@ -19,34 +19,37 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
     out_gn = (samples, rows_per_sample, groups) of the GroupNorm that reads `out` as the very next op (the norm in front of
     the transformer / motion module / ResNet block behind this one), or None: a split-K conv2 then leaves its statistics."""
     g = geo
-    if getattr(w, "wino1", None) is not None:
-        # Winograd F(2x2, 3x3) form of both convolutions (wino_level): the norms are statistics-only launches, their apply + SiLU
-        # rides in the input transforms; conv_shortcut(x) as four parity GEMMs of conv2's batched launch
-        assert not dup_rows and x.C == w.cin
-        rv = (temb[0], temb[1], temb[2], g.f * g.hw)
-        gn1 = emit_groupnorm_stats(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, groups)
-        h1 = plan.rows("res_h1", g.M, w.cout)
+    u1, u2 = getattr(w, "wino1", None) is not None, getattr(w, "wino2", None) is not None
+    rv = (temb[0], temb[1], temb[2], g.f * g.hw)
+    cross = (g.b, g.f * g.hw, groups)
+    assert not (u1 or u2) or (not dup_rows and x.C == w.cin)
+    h1 = plan.rows("res_h1", g.M, w.cout)
+    # ---- norm1 + conv1.  Winograd form (wino_level): the norm is a statistics-only launch, its apply + SiLU rides in the input
+    # transform; its output transform leaves norm2's per-tile statistics when conv2 takes that form too
+    res = x
+    if u1:
+        gn1 = emit_groupnorm_stats(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, groups)   # (first: x may carry a producer's statistics)
         emit_conv3x3_wino(plan, x, g.n_img, g.H, g.W, w.wino1, w.cin, w.cout, h1, bias=w.cb1, rowvec=rv, gn=gn1,
-                          gn_out=(g.b, g.f * g.hw, groups))
+                          gn_out=cross if u2 else None)
+    else:
+        a1 = plan.rows("norm", g.M, x.C)
+        emit_groupnorm(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, True, a1, groups)   # (first: x may carry a producer's statistics)
+        if not u2 and w.shortcut is not None:
+            res = plan.rows("res_sc", g.M, w.cout)
+            emit_gemm(plan, x, w.shortcut, w.cout, w.cin, res, bias=w.sb)
+        emit_conv3x3(plan, a1, g.n_img, g.H, g.W, w.conv1, w.cin, w.cout, h1, bias=w.cb1, rowvec=rv, gn=cross)
+    # ---- norm2 + conv2 (+ conv_shortcut(x) | + x)
+    if u2:
         gn2 = emit_groupnorm_stats(plan, h1, g.b, g.f * g.hw, w.g2, w.b2, eps, groups)
-        if w.shortcut is not None:
+        if w.shortcut is not None:   # conv_shortcut(x) as four parity GEMMs of conv2's batched launch
             emit_conv3x3_wino(plan, h1, g.n_img, g.H, g.W, w.wino2, w.cout, w.cout, out, bias=w.cb2sc, scale=out_scale, gn=gn2,
                               x2=x, W2=w.shortcut)
         else:
             emit_conv3x3_wino(plan, h1, g.n_img, g.H, g.W, w.wino2, w.cout, w.cout, out, bias=w.cb2, residual=x, scale=out_scale,
                               gn=gn2)
         return
-    a1 = plan.rows("norm", g.M, x.C)
-    emit_groupnorm(plan, x, g.b, g.f * g.hw, w.g1, w.b1, eps, True, a1, groups)   # (first: x may carry a producer's statistics)
-    res = x
     fold_sc = w.conv2sc is not None
     assert not fold_sc or x.C == w.cin
-    if w.shortcut is not None:
-        res = plan.rows("res_sc", g.M, w.cout)
-        emit_gemm(plan, x, w.shortcut, w.cout, w.cin, res, bias=w.sb)
-    h1 = plan.rows("res_h1", g.M, w.cout)
-    emit_conv3x3(plan, a1, g.n_img, g.H, g.W, w.conv1, w.cin, w.cout, h1, bias=w.cb1,
-                 rowvec=(temb[0], temb[1], temb[2], g.f * g.hw), gn=(g.b, g.f * g.hw, groups))
     a2 = plan.rows("norm", g.M, w.cout)
     emit_groupnorm(plan, h1, g.b, g.f * g.hw, w.g2, w.b2, eps, True, a2, groups)
     if fold_sc:   # (resnet.py:205-212 with a conv_shortcut: its 1x1 convolution of x rides in conv2's accumulators)
@@ -58,14 +61,19 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
 
 
 WINO_MIN_CHANNELS = 640   # k-loops of >= 10 steps per position GEMM; narrower convs keep the nine-tap form at every size
+WINO_SHORTCUT_MIN_SIDE = 16   # below: a conv2 that carries a conv_shortcut keeps the nine-tap form (measured 49 against 47 us at 8x8)
 
 
 def wino_level(geo, cin, cout):
-    """Whether the ResNet blocks of this geometry take the Winograd form of their 3x3 convolutions (switches.WINO: the latent
+    """(conv1, conv2): which 3x3 convolutions of a ResNet block of this geometry take the Winograd form (switches.WINO: the latent
     sides it is used at — where the nine-tap implicit GEMM is a split-K latency chain, not a stream)."""
-    return (geo.H == geo.W and geo.H in SW.WINO and min(cin, cout) >= WINO_MIN_CHANNELS and
-            conv3x3_wino_ok(geo.n_img, geo.H, geo.W, cin, cout) and
-            conv3x3_wino_ok(geo.n_img, geo.H, geo.W, cout, cout, cin if cin != cout else 0))
+    if not (geo.H == geo.W and geo.H in SW.WINO):
+        return (False, False)
+    u1 = min(cin, cout) >= WINO_MIN_CHANNELS and conv3x3_wino_ok(geo.n_img, geo.H, geo.W, cin, cout)
+    cin2 = cin if cin != cout else 0
+    u2 = (cout >= WINO_MIN_CHANNELS and (not cin2 or geo.H >= WINO_SHORTCUT_MIN_SIDE) and
+          conv3x3_wino_ok(geo.n_img, geo.H, geo.W, cout, cout, cin2))
+    return (u1, u2)
 
 
 # a chain launch (rcdm_rowchain / rcdm_ff_fused, rowff.hip) is one block of 160 rows per CU: below ~3/4 of a chip's worth of

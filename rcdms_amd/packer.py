@@ -183,22 +183,27 @@ class Packer:
         self._tmp.clear()
 
 
-def pack_resnet(pk, p, wino=False):
-    """wino: the block's two 3x3 convolutions in the Winograd form (w.wino1 / w.wino2 instead of w.conv1 / w.conv2; the 1x1
-    conv_shortcut stays a plain f16 matrix, w.shortcut, and rides as four parity GEMMs of the same launch)."""
+def pack_resnet(pk, p, wino=(False, False)):
+    """wino = (conv1, conv2): which of the block's two 3x3 convolutions take the Winograd form (w.wino1 / w.wino2 instead of
+    w.conv1 / w.conv2; with w.wino2 the 1x1 conv_shortcut stays a plain f16 matrix, w.shortcut, and rides as four parity GEMMs
+    of conv2's batched launch)."""
     w = _NS(cin=pk.sd[p + "conv1.weight"].shape[1], cout=pk.sd[p + "conv1.weight"].shape[0])
     w.g1, w.b1 = pk.vec(p + "norm1.weight"), pk.vec(p + "norm1.bias")
     w.g2, w.b2 = pk.vec(p + "norm2.weight"), pk.vec(p + "norm2.bias")
-    w.wino1 = None
-    if wino and w.cin % 64 == 0 and w.cout % 64 == 0:
-        w.wino1, w.cb1 = pk.conv3x3_wino(p + "conv1.weight"), pk.vec(p + "conv1.bias")
+    u1, u2 = (bool(wino), bool(wino)) if isinstance(wino, bool) else wino
+    w.wino1 = w.wino2 = None
+    if u1:
+        w.wino1, w.cb1, w.conv1 = pk.conv3x3_wino(p + "conv1.weight"), pk.vec(p + "conv1.bias"), None
+    if u2:
         w.wino2, w.cb2 = pk.conv3x3_wino(p + "conv2.weight"), pk.vec(p + "conv2.bias")
-        w.conv1 = w.conv2 = w.shortcut = w.conv2sc = None
+        w.conv2 = w.shortcut = w.conv2sc = None
         if pk.has(p + "conv_shortcut.weight"):
             w.shortcut, w.sb = pk.mat_f16(p + "conv_shortcut.weight"), pk.vec(p + "conv_shortcut.bias")
             w.cb2sc = (w.cb2 + w.sb).contiguous()
+    if not u1:
+        w.conv1, w.cb1 = pk.conv3x3(p + "conv1.weight"), pk.vec(p + "conv1.bias")
+    if u2:
         return w
-    w.conv1, w.cb1 = pk.conv3x3(p + "conv1.weight"), pk.vec(p + "conv1.bias")
     w.conv2, w.cb2 = pk.conv3x3(p + "conv2.weight"), pk.vec(p + "conv2.bias")
     w.shortcut = w.conv2sc = None
     if pk.has(p + "conv_shortcut.weight"):

@@ -20,7 +20,7 @@ ROW_CHAIN = _on("RCDM_ROWCHAIN")     # 0: separate launches instead of the row-s
 RANK1_CTX = _on("RCDM_RANK1_CTX")    # 0: cross-attention evaluated in full even for images whose context rows are all equal
 # latent sides (comma list) whose stride-1 3x3 convolutions of the ResNet blocks take the Winograd F(2x2, 3x3) form (rcdm_conv3x3_wino,
 # with the GroupNorm apply + SiLU in its input transform) instead of the nine-tap implicit GEMM; "0" = none (resnet.py:182-212)
-WINO = tuple(int(v) for v in os.environ.get("RCDM_WINO", "16").split(",") if v.strip() and int(v) > 0)
+WINO = tuple(int(v) for v in os.environ.get("RCDM_WINO", "32,16,8").split(",") if v.strip() and int(v) > 0)
 CHAIN_MIN_ROWS = os.environ.get("RCDM_CHAIN_MIN_ROWS")   # token rows from which the chains are used (default: 3/4 of a chip of 160-row blocks)
 
 TABLE = {

@@ -49,8 +49,18 @@ def _rel_rms(got, ref):
     (2, 5, 8, 8, 1280, 0, 1280, 1 | 4, 0, False),    # the 8x8 level: 160 tiles, heuristic split-K
     (2, 5, 8, 8, 2560, 0, 1280, 1 | 2, 0, True),
 ])
-def test_conv3x3_wino(hiplib, b, f, H, W, cin, cin2, cout, epi, split, gn):
+@pytest.mark.parametrize("slab16", [0, 1])
+def test_conv3x3_wino(hiplib, b, f, H, W, cin, cin2, cout, epi, split, gn, slab16):
+    """slab16: rcdm_set_wino_slab_f16 — the transform-domain sums between the batched GEMM and the output transform in f16."""
     from rcdms_amd import hip
+    hip.set_wino_slab_f16(slab16)
+    try:
+        _conv3x3_wino(hip, b, f, H, W, cin, cin2, cout, epi, split, gn, slab16)
+    finally:
+        hip.set_wino_slab_f16(-1)
+
+
+def _conv3x3_wino(hip, b, f, H, W, cin, cin2, cout, epi, split, gn, slab16):
     g = torch.Generator().manual_seed(900 + cin + cin2 + cout + H)
     x = h16(torch.randn(b, cin, f, H, W, generator=g) * 1.5 + 0.3)
     w = h16(torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
@@ -130,7 +140,7 @@ def test_conv3x3_wino(hiplib, b, f, H, W, cin, cin2, cout, epi, split, gn):
         hip.conv3x3(d1, a1.data_ptr(), wp.data_ptr(), *args)
     torch.cuda.synchronize()
     e_w, e_d = _rel_rms(got, ref), _rel_rms(rows_to_5d(out1, b, cout, f, H, W), ref)
-    print(f"rel-RMS vs fp32 oracle: winograd {e_w:.3e}, nine-tap {e_d:.3e}, ratio {e_w / max(e_d, 1e-12):.2f}")
+    print(f"rel-RMS vs fp32 oracle: winograd{' (f16 slabs)' if slab16 else ''} {e_w:.3e}, nine-tap {e_d:.3e}, ratio {e_w / max(e_d, 1e-12):.2f}")
     assert e_w <= 3.0 * e_d + 1e-4, (e_w, e_d)
 
 
