@@ -50,6 +50,9 @@ def level_of(tag):
     rows = None
     if kind in ("gemm", "rowchain", "ff_fused", "layernorm"):
         rows = kv.get("M")
+    elif kind == "conv3x3_wino":
+        n, H, W = (float(v) for v in re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
+        rows = n * H * W
     elif kind == "conv3x3":
         n, H, W = (float(v) for v in re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
         rows = n * H * W * (4.0 if kv.get("up") else 1.0) / (kv.get("s", 1.0) ** 2)
@@ -263,7 +266,7 @@ def main():
     print(f"\n# reading: the step spends {tt:.2f} ms in sequence ({graph_ms:.2f} ms as a replayed graph).  With every contraction at the best "
           f"isolated WARM rate any tile of this library reaches on its exact shape it would spend {tb:.2f} ms (the {tt - tb:.2f} ms between the two "
           f"are cold operands + launch ramps, not tile choice); with every contraction at the {YARDSTICK_TFLOPS:.0f} TFLOP/s of the 4096^3 yardstick, "
-          f"{ty:.2f} ms = {11.044 / ty:.0f} TFLOP/s = {100 * 11.044 / ty / 2500:.1f} % of the 2.5 PFLOP/s peak — the ceiling of this decomposition "
+          f"{ty:.2f} ms = {11044 / ty:.0f} TFLOP/s = {100 * 11044 / ty / 2500:.1f} % of the 2.5 PFLOP/s peak — the ceiling of this decomposition "
           "(one launch per GEMM-shaped op at b f = 10 images, non-contraction launches as they are).")
 
 

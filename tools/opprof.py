@@ -30,6 +30,10 @@ def algorithmic_work(tag):
         cin, cout = (float(v) for v in re.search(r"(\d+)->(\d+)", tag).groups())
         rows = n * H * W * (4.0 if kv.get("up") else 1.0) / (kv.get("s", 1.0) ** 2)
         return 2e-9 * rows * (9 * cin + kv.get("add1x1", 0.0)) * cout, None   # (add1x1: the folded conv_shortcut's channels)
+    if kind == "conv3x3_wino":   # priced at the reference's nine taps; the Winograd form multiplies 16 / 36 of them
+        n, H, W = (float(v) for v in re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
+        cin, cout = (float(v) for v in re.search(r"(\d+)->(\d+)", tag).groups())
+        return 2e-9 * n * H * W * (9 * cin + kv.get("add1x1", 0.0)) * cout, None
     if kind in ("flash_attn", "xattn", "flash_attn_masked"):
         Lk = kv.get("Lk", kv.get("L", 0))
         Lq = kv.get("Lq", kv.get("L", 0))
