@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RCDM_VERSION 0x000200 /* 0.2.0 */
+#define RCDM_VERSION 0x000300 /* 0.3.0: + rcdm_conv3x3_wino*, rcdm_groupnorm_stats_prestat / _finalize (no descriptor changed) */
 /* ABI rule: every descriptor struct below MUST be zero-initialised by the caller (memset / `= {0}` / calloc) before its
  * fields are set.  Descriptors grow at the END between versions and a zero in a field this header does not describe yet
  * always means "the behaviour of the previous version": 0.2.0 added rcdm_conv3x3_desc.c_in2 / lda2 (rcdm_conv3x3_add1x1)

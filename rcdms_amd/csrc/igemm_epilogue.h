@@ -43,6 +43,53 @@ __device__ __forceinline__ void lnx_write_tables(const IgemmArgs& p, float* tab,
 }
 constexpr int lnx_table_bytes(int BM, int BN) { return (2 * BM + 3 * BN) * 4; }
 
+// fp32 tile -> slab through LDS, whole rows per store instruction (round 6).  The accumulator layout gives a lane 4 consecutive
+// channels of ONE row: stored directly, a wave's store instruction covers 16 rows x 64 bytes — half-line pieces the memory system
+// merges badly (the fp32 slab epilogue of the 16x16-level Winograd GEMM cost 15 us where the f16 staged one cost 5).  Here the
+// tile goes through LDS in passes of RP rows ([RP][BN] floats, rows padded by 16 B): every wave writes the fragments whose rows
+// fall in the pass, then all NT threads store 16 bytes per lane along the rows (BN * 4 contiguous bytes per row).
+// Caller: every wave past its k-loop and past a barrier (the ring is free); RP % 16 == 0, RP * (4 BN + 16) bytes of LDS at stg.
+template <int FMW, int FNW, int NT, int BM, int BN, int RP>
+__device__ __forceinline__ void slab_store_staged(float* dst, int ldn, int Mlim, int Nlim, char* stg, f32x4 (&acc)[FNW][FMW],
+                                                  int cm0, int cn0, int row0, int col0, int l15, int kg, int t) {
+  static_assert(RP % 16 == 0 && BM % RP == 0, "pass rows");
+  constexpr int RS = 4 * BN + 16;
+  constexpr int CPR = BN / 4, ITEMS = RP * CPR;
+#pragma unroll
+  for (int pass = 0; pass < BM / RP; ++pass) {
+#pragma unroll
+    for (int j = 0; j < FMW; ++j) {
+      const int row = row0 + j * 16 + l15 - pass * RP;
+      if ((row0 + j * 16) / RP == pass) {   // (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < FNW; ++i) *(f32x4*)(stg + row * RS + (col0 + i * 16 + 4 * kg) * 4) = acc[i][j];
+      }
+    }
+    wait_lgkm0();
+    tick_barrier();
+    for (int base = 0; base < ITEMS; base += NT * 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = min(base + u * NT + t, ITEMS - 1);
+        const int row = idx / CPR, c = idx - row * CPR;
+        v[u] = *(const f32x4*)(stg + row * RS + c * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * NT + t;
+        const int row = idx / CPR, c = idx - row * CPR;
+        const int m = cm0 + pass * RP + row, n = cn0 + c * 4;
+        if (idx < ITEMS && m < Mlim && n < Nlim) *(f32x4*)(dst + (size_t)m * ldn + n) = v[u];
+      }
+    }
+    if (pass + 1 < BM / RP) {
+      wait_lgkm0();
+      tick_barrier();   // everybody has read this pass before the next one overwrites it
+    }
+  }
+}
+
 // stg: where the f16 staging tile goes ([BM] rows of 2 BN + 16 bytes); ltab: the tables lnx_write_tables left (nullptr: none)
 template <int FMW, int FNW, bool SLAB, int NT, int BM, int BN, bool LN_OK = false, bool LX = false, bool PH = false>  // LX: rcdm_gemm_lnx consumer epilogues compiled in (GEMM launches only); PH: phase launch (bias-only epilogues, rows remapped)
 __device__ __forceinline__ void tile_epilogue(const IgemmArgs& p, char* stg, f32x4 (&acc)[FNW][FMW], int cm0, int cn0,

@@ -604,10 +604,15 @@ bool gn_single_launch(const GnArgs& a) {
     const char* e = getenv("RCDM_GN_FUSED");
     fused_mode = e ? atoi(e) : 1;
   }
+  static int fused_rows = -1;  // RCDM_GN_FUSED_ROWS: rows per sample up to which the single-launch form is used
+  if (fused_rows < 0) {
+    const char* e = getenv("RCDM_GN_FUSED_ROWS");
+    fused_rows = e ? atoi(e) : 512;
+  }
   const int gb = gn_fused_bundle(a.G, a.cg);
   // one block per (sample, bundle) pays up to a few hundred rows per sample (measured: 15 -> 9 us at 320 rows, but
   // 17 -> 22 us at 1280 and 25 -> 64 us at 4096: a single block streams its slab too slowly)
-  return fused_mode && gb && a.samples * (a.G / gb) >= 48 && a.P <= 512;
+  return fused_mode && gb && a.samples * (a.G / gb) >= 48 && a.P <= fused_rows;
 }
 
 // finalize + apply of the three-launch form (partials already in a.partial)

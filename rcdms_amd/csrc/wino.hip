@@ -279,17 +279,10 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs p) {
     q.M = p.T; q.N = p.N; q.ldc = p.N; q.epi = 0; q.out_scale = 1.0f; q.dup = 0;
     tile_epilogue<FM, FN, false, 256, BM, BN, false, false>(q, smem, acc, cm0, cn0, row0, col0, l15, kg, t, nullptr);
   } else {
-    // fp32 tile to the slab: 16 B per lane, 64-byte runs per tile row (an empty slice — more splits than k-steps — writes zeros)
-    float* const dst = p.slab + slab_off;
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = cm0 + row0 + j * 16 + l15;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int n = cn0 + col0 + i * 16 + 4 * kg;
-        if (m < p.T && n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
-      }
-    }
+    // fp32 tile to the slab, whole rows per store through LDS (an empty slice — more splits than k-steps — writes zeros)
+    wait_lgkm0();
+    tick_barrier();   // every wave is done reading the ring
+    slab_store_staged<FM, FN, 256, BM, BN, 80>(p.slab + slab_off, p.N, p.T, p.N, smem, acc, cm0, cn0, row0, col0, l15, kg, t);
   }
 }
 

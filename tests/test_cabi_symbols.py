@@ -24,7 +24,7 @@ def test_build_and_exports():
         assert hasattr(lib, n), f"{n} declared in include/rcdm.h but not exported"
     from rcdms_amd import hip
     assert sorted(hip.SYMBOLS) == names, "ctypes binding and header disagree"
-    assert hip.load().rcdm_version() == 0x000200
+    assert hip.load().rcdm_version() == 0x000300
 
 
 def test_argument_validation_without_gpu():

@@ -4,5 +4,5 @@
 cd "$(dirname "$0")/.."
 R=$1; shift
 for i in $(seq $R); do for v in "$@"; do
-  RCDM_LIB=$PWD/rcdms_amd/lib/librcdm_$v.so timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lib=$v', d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"
+  RCDM_LIB=$PWD/rcdms_amd/lib/librcdm_$v.so timeout 300 python bench.py --no-cpu-baseline --no-extra-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lib=$v', d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"
 done; done

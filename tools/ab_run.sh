@@ -11,5 +11,5 @@ for e in old new; do
 done > gpurun_out/ab.log 2>&1
 for e in old new old new; do
   L=$PWD/rcdms_amd/lib/librcdm_hip.so; [ $e = old ] && L=$PWD/rcdms_amd/lib/librcdm_old.so
-  RCDM_LIB=$L timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$e', d['value'], d['ms_per_step'])"
+  RCDM_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-extra-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$e', d['value'], d['ms_per_step'])"
 done

@@ -11,7 +11,7 @@ out=gpurun_out/clock_probe.txt
   echo "== static"
   rocm-smi --showperflevel --showpowercap --showmaxpower --showclocks --showtemp 2>&1 | grep -v "^$" | head -60
 } >> "$out"
-python bench.py --no-cpu-baseline "$@" > gpurun_out/clock_probe_bench.json 2> gpurun_out/clock_probe_bench.err &
+python bench.py --no-cpu-baseline --no-extra-configs "$@" > gpurun_out/clock_probe_bench.json 2> gpurun_out/clock_probe_bench.err &
 bp=$!
 : > gpurun_out/clock_probe_samples.txt
 while kill -0 $bp 2>/dev/null; do

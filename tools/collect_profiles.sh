@@ -8,10 +8,10 @@ tag=${1:-r1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 mkdir -p "$out"
-timeout 400 rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- python bench.py --steps 1 --warmup 0 --ddim-steps 4 --no-cpu-baseline > "$out/trace.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- python bench.py --steps 1 --warmup 0 --ddim-steps 4 --no-cpu-baseline --no-extra-configs > "$out/trace.log" 2>&1
 python tools/prof_summary.py "$out/trace" 5 < /dev/null > "$out/kernel_stats.txt"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $c -d "$out/pmc_$c" -o p -- python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline --no-graph > "$out/pmc_$c.log" 2>&1
+  timeout 400 rocprofv3 --pmc $c -d "$out/pmc_$c" -o p -- python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline --no-extra-configs --no-graph > "$out/pmc_$c.log" 2>&1
 done
 python tools/hbm_traffic.py "$out" 2 < /dev/null > "$out/hbm_traffic.json"
 rm -rf "$out/trace" "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE   # raw rocpd databases: tens of MB, summaries are kept

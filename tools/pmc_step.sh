@@ -13,7 +13,7 @@ for set in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  timeout 400 rocprofv3 --pmc $set -d "$out/p$i" -o p -- python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline --no-graph > "$out/p$i.log" 2>&1 < /dev/null
+  timeout 400 rocprofv3 --pmc $set -d "$out/p$i" -o p -- python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline --no-extra-configs --no-graph > "$out/p$i.log" 2>&1 < /dev/null
 done
 python tools/pmc_summary.py "$out" < /dev/null > "$out/pmc.txt"
 rm -rf "$out"/p[0-9]   # raw rocpd databases

@@ -13,11 +13,7 @@ bash tools/pmc_step.sh "${tag}_pmc" > "$out/pmc.log" 2>&1
 python tools/opprof.py --top 1000 > "$out/opprof.txt" 2>&1
 python tools/level_summary.py "$out/opprof.txt" > "$out/levels.txt" 2>&1
 python tools/soak.py 8 > "$out/soak.txt" 2>&1
-{
-  python bench.py --no-cpu-baseline
-  python bench.py --no-cpu-baseline --latent 32 --ddim-steps 20
-  python bench.py --no-cpu-baseline --stories 4 --ctx-len 91 --steps 2
-  python tools/bench_prior.py
+{   # (configs 1 / 3 / 5 and the reference-context story are in the bench line's extra_configs since round 6)
   python tools/bench_vae.py
 } > "$out/other_configs.jsonl" 2> "$out/other.err"
 tail -1 "$out/bench_line.json" | cut -c1-600; tail -3 "$out/soak.txt"; tail -6 "$out/levels.txt"; cat "$out/hbm_traffic.json" | head -8
