@@ -44,6 +44,23 @@ __device__ __forceinline__ void load8(const float* src, float (&d)[8]) {
   d[4] = b[0]; d[5] = b[1]; d[6] = b[2]; d[7] = b[3];
 }
 
+// v[0..8) += eight consecutive slab values at element offset `off` (fp32 slabs, or f16 ones: IgemmArgs::slab16)
+__device__ __forceinline__ void slab_add8(const IgemmArgs& p, size_t off, float (&v)[8]) {
+  if (p.slab16) {
+    Pack16 h;
+    h.u = *(const uint4*)((const f16*)p.partial + off);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)h.e[e];
+  } else {
+    const f32x4 a = *(const f32x4*)(p.partial + off), b = *(const f32x4*)(p.partial + off + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] += a[e];
+      v[4 + e] += b[e];
+    }
+  }
+}
+
 __device__ __forceinline__ uint4 epilogue_store(const IgemmArgs& p, int m, int n, float (&v)[8], float (&g)[8]) {   // returns the 8 halfs it stored
   int oc = n;
   if (p.epi & RCDM_EPI_GEGLU) {
@@ -744,21 +761,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = g[e] = 0.f;
     for (int s = 0; s < p.splits; ++s) {
-      const float* src = p.partial + ((size_t)s * p.M + m) * p.N + n;
-      const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] += a[e];
-        v[4 + e] += b[e];
-      }
-      if (geglu) {
-        const f32x4 c = *(const f32x4*)(src + kGegluGroup), d = *(const f32x4*)(src + kGegluGroup + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          g[e] += c[e];
-          g[4 + e] += d[e];
-        }
-      }
+      const size_t off = ((size_t)s * p.M + m) * p.N + n;
+      slab_add8(p, off, v);
+      if (geglu) slab_add8(p, off + kGegluGroup, g);
     }
     epilogue_store(p, p.ph_rows ? phase_out_row(p, m) : m, n, v, g);   // (phase launches carry a bias at most: no per-row operand)
   }
@@ -792,6 +797,19 @@ __global__ __launch_bounds__(512) void splitk_reduce_gn_kernel(const IgemmArgs p
       for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
     // (both slabs of a split-2 launch requested together — 210 VGPRs — measured +0.06 ms per step against this form)
     for (int k = 0; k < p.splits; ++k) {
+      if (p.slab16) {
+        Pack16 h[GN_U];
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+          const int ru = min(r + u * p.gn_RPB, r_end - 1);
+          h[u].u = *(const uint4*)((const f16*)p.partial + ((size_t)k * p.M + (size_t)s * p.gn_P + ru) * p.N + n);
+        }
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[u][e] += (float)h[u].e[e];
+        continue;
+      }
       f32x4 a[GN_U], b[GN_U];
 #pragma unroll
       for (int u = 0; u < GN_U; ++u) {
@@ -849,6 +867,15 @@ int launch_splitk_reduce(const IgemmArgs& a, hipStream_t stream) {
 // 5 = 128x64 (3); 6 / 7 / 8 = the ping-pong kernel of igemm8.hip at 160x320 / 160x256 / 256x256; 9 = the 160x160 kernel of
 // igemm16.hip (2); 10 = 128x64 with a three-slot ring (2; GEMMs)   (-1 = heuristic)
 int g_force_variant = -1;
+// f16 split-K slabs on the 160x160 kernel (IgemmArgs::slab16): -1 = not set (environment RCDM_SLAB16, default below)
+int g_slab16 = -1;
+int slab16_mode() {
+  if (g_slab16 < 0) {
+    const char* e = getenv("RCDM_SLAB16");
+    g_slab16 = e ? (atoi(e) != 0) : 0;
+  }
+  return g_slab16;
+}
 struct TileCfg { int bm, bn, blocks_per_cu; };
 constexpr int kFirstPP = 6;
 constexpr int kVar16 = 9;  // igemm16.hip: 160x160, two blocks per CU
@@ -1226,6 +1253,7 @@ int launch(IgemmArgs& a, int variant, void* workspace, size_t workspace_bytes, h
   if (a.lnx_stat && (a.splits > 1 || !a.lnx_S || a.lnx_parts < 1 || a.lnx_parts > kLnxMaxParts)) return RCDM_ESHAPE;
   if (a.lnx_stat && variant == kFirstPP + 2) return RCDM_ESHAPE;   // the 256x256 ping-pong tile has no consumer epilogue (register cap); only reachable when that variant is forced
   if (variant == kVar16) {
+    a.slab16 = a.splits > 1 && slab16_mode() && !(a.epi & RCDM_EPI_GEGLU);
     int rc = rcdm_igemm16_launch(a, TAPS, stream);
     if (rc) return rc;
     if (a.splits > 1) {
@@ -1447,6 +1475,11 @@ int rcdm_set_shape_rules(const char* rules) {
   g_rules_from_api = rules != nullptr;
   if (rules) strcpy(g_rules_text, rules);
   g_n_env = -1;   // parsed again at the next launch
+  return RCDM_OK;
+}
+
+int rcdm_set_splitk_slab_f16(int32_t on) {
+  g_slab16 = on < 0 ? -1 : (on ? 1 : 0);
   return RCDM_OK;
 }
 

@@ -217,6 +217,15 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(const IgemmArgs p) {
     if (s == 1.2345678e33f) p.out[0] = (f16)s;
   }
 #else
+  if constexpr (SLAB) {
+    if (p.slab16) {   // f16 slab: the plain-projection path of the staged epilogue, pointed at this split's slab
+      IgemmArgs q{};
+      q.out = (f16*)p.partial + (size_t)blockIdx.y * p.M * p.N;
+      q.M = p.M; q.N = p.N; q.ldc = p.N; q.epi = 0; q.out_scale = 1.0f; q.dup = 0;
+      tile_epilogue<FM, FN, false, 256, BM, BN, false, false>(q, smem, acc, cm0, cn0, wm * (BM / 2), wn * (BN / 2), l15, kg, t, nullptr);
+      return;
+    }
+  }
   tile_epilogue<FM, FN, SLAB, 256, BM, BN, false, TAPS == 1 && !SLAB>(p, stg, acc, cm0, cn0, wm * (BM / 2), wn * (BN / 2), l15, kg, t,
                                                                        lx_on ? lx_tab : nullptr);
 #endif

@@ -158,6 +158,7 @@ SYMBOLS = {
     "rcdm_conv3x3_wino_plan_query": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     "rcdm_pack_conv3x3_wino": (C.c_int, [_P, _I, _I, _P, _P]),
     "rcdm_set_wino_slab_f16": (C.c_int, [_I]),
+    "rcdm_set_splitk_slab_f16": (C.c_int, [_I]),
     "rcdm_conv3x3_wino": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                     C.POINTER(GroupNormDesc), _P, _P]),
     "rcdm_groupnorm_finalize": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P]),
@@ -522,6 +523,10 @@ def pack_conv3x3_up2(w, c_out, c_in, dst, stream=None):
 
 def conv3x3_up2_supported(desc):
     return bool(load().rcdm_conv3x3_up2_supported(C.byref(desc)))
+
+
+def set_splitk_slab_f16(on):
+    _check(load().rcdm_set_splitk_slab_f16(on), "rcdm_set_splitk_slab_f16")
 
 
 def set_wino_slab_f16(on):
