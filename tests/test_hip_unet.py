@@ -137,6 +137,26 @@ def test_full_unet_plan_folds_the_resnet_shortcuts(full_unet):
     assert widths == sorted([320, 640] + [2560] * 5 + [1920] * 2 + [1280] + [960] * 2 + [640] * 2), widths
 
 
+def test_full_unet_plan_takes_the_winograd_form(full_unet):
+    """Round 6: at 64x64 latents the ResNet blocks of the 32x32 / 16x16 / 8x8 levels (>= 640 channels) run their stride-1 3x3
+    convolutions as rcdm_conv3x3_wino (switches.WINO) — 17 blocks, 31 launches: every conv1 with >= 640 input channels, every
+    conv2 except the three that carry a conv_shortcut at the 8x8 level — each fed by a statistics-only GroupNorm (the apply rides
+    in the input transform), and no Winograd launch appears at the 64x64 level.  (The goldens above run through exactly this plan.)"""
+    from rcdms_amd import switches as SW
+    if tuple(SW.WINO) != (32, 16, 8):
+        pytest.skip("RCDM_WINO overridden")
+    full_unet(torch.zeros(2, 9, 5, 64, 64, device=DEV), torch.tensor(981), torch.zeros(10, 85, 768, device=DEV), return_dict=False)
+    tags = full_unet.program(2, 5, 64, 64, 85).plan.tags
+    wino = [t for t in tags if t.startswith("conv3x3_wino ")]
+    assert len(wino) == 30, len(wino)          # 16 conv1 (down_blocks.1.resnets.0 has 320 input channels) + 14 conv2
+    assert not any("x64x64 " in t for t in wino)
+    assert all(" gn" in t for t in wino)
+    # conv1 -> norm2 hand-off: the output transform leaves the statistics wherever conv2 is a Winograd conv too
+    assert sum(" gnstat" in t for t in wino) == 13
+    nine_tap_low = [t for t in tags if t.startswith("conv3x3 ") and " s=1 up=0 " in t and "x64x64 " not in t]
+    assert len(nine_tap_low) == 4, nine_tap_low     # conv1 of the 320 -> 640 block + the three 8x8 conv2 with a shortcut
+
+
 @pytest.mark.parametrize("hw", [32, 64])
 def test_full_unet_eps_along_trajectory(full_unet, hw):
     """eps-parity at mid / late points of the denoising trajectory: the HIP UNet's raw output at the REFERENCE

@@ -160,3 +160,64 @@ def test_conv3x3_wino_refusals(hiplib):
     x = torch.zeros(4096, dtype=torch.float16, device=DEV)
     with pytest.raises(hip.RcdmError):   # workspace too small
         hip.conv3x3_wino(ok, x.data_ptr(), x.data_ptr(), 0, 0, 0, x.data_ptr(), x.data_ptr(), 16)
+
+
+def test_conv3x3_wino_random_shapes(hiplib):
+    """Seeded sweep: image counts and sides that leave partly filled 160-row tiles, channel counts with N tails, padded row
+    strides, every epilogue combination, forced split-K, second input, the norm in the input transform — against fp32."""
+    import random
+    from rcdms_amd import hip
+    rnd = random.Random(606)
+    for case in range(24):
+        b, f = rnd.choice([(1, 1), (1, 3), (2, 1), (2, 5), (3, 2)])
+        H, W = 2 * rnd.randint(1, 6), 2 * rnd.randint(1, 6)
+        cin, cout = 64 * rnd.randint(1, 4), 8 * rnd.randint(1, 40)
+        cin2 = rnd.choice([0, 0, 64, 128])
+        gn = rnd.random() < 0.5
+        epi = rnd.choice([0, 1]) | rnd.choice([0, 2]) | rnd.choice([0, 4])
+        split = rnd.choice([0, 0, 1, 2, 3])
+        scale = rnd.choice([1.0, 0.5, 1 / 1.3])
+        g = torch.Generator().manual_seed(7000 + case)
+        x = h16(torch.randn(b, cin, f, H, W, generator=g) * 1.3 - 0.2)
+        w = h16(torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
+        bias, temb = torch.randn(cout, generator=g), torch.randn(b, cout, generator=g)
+        res = h16(torch.randn(b, cout, f, H, W, generator=g))
+        gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+        xin = F.silu(O.group_norm_cross_frame(x, gamma, beta, 32, 1e-5)) if gn else x
+        ref = O.conv_frames(xin, w, bias if epi & 1 else None, stride=1, padding=1)
+        x2d = w2d = None
+        lda, lda2, ldc, ldr = cin + 8 * rnd.randint(0, 2), cin2 + 8 * rnd.randint(0, 2), cout + 8 * rnd.randint(0, 2), cout + 8 * rnd.randint(0, 2)
+        if cin2:
+            x2 = h16(torch.randn(b, cin2, f, H, W, generator=g))
+            w2 = h16(torch.randn(cout, cin2, generator=g) * cin2 ** -0.5)
+            ref = ref + torch.einsum("oc,bcfhw->bofhw", w2, x2)
+            x2d, w2d = rows_from_5d(x2, lda2), w2.half().to(DEV).contiguous()
+        if epi & 2:
+            ref = ref + temb[:, :, None, None, None]
+        if epi & 4:
+            ref = ref + res
+        ref = ref * scale
+        xd, rd = rows_from_5d(x, lda), rows_from_5d(res, ldr)
+        w32 = w.to(DEV)
+        U = torch.empty(16, cout, cin, dtype=torch.float16, device=DEV)
+        hip.pack_conv3x3_wino(w32.data_ptr(), cout, cin, U.data_ptr())
+        bd, td, gd, bed = bias.to(DEV), temb.to(DEV), gamma.to(DEV), beta.to(DEV)
+        M = b * f * H * W
+        out = torch.full((M, ldc), float("nan"), dtype=torch.float16, device=DEV)
+        d = hip.ConvDesc(b * f, H, W, cin, cout, 1, 0, lda, ldc, ldr if epi & 4 else 0, epi, f * H * W, cout, scale, split, 0, 0, cin2,
+                         lda2 if cin2 else 0)
+        assert hip.conv3x3_wino_supported(d), (case, b, f, H, W, cin, cout)
+        gnd = stat = None
+        if gn:
+            gnd = hip.GroupNormDesc(b, f * H * W, cin, 32, lda, lda, 1e-5, 1)
+            stat = torch.empty(b * 32 * 2, dtype=torch.float32, device=DEV)
+            gws = ws(hip.groupnorm_workspace_bytes(gnd))
+            hip.groupnorm_stats(gnd, xd.data_ptr(), stat.data_ptr(), gws.data_ptr(), gws.numel())
+        wsb = ws(hip.conv3x3_wino_workspace_bytes(d))
+        hip.conv3x3_wino(d, xd.data_ptr(), U.data_ptr(), bd.data_ptr() if epi & 1 else 0, td.data_ptr() if epi & 2 else 0,
+                         rd.data_ptr() if epi & 4 else 0, out.data_ptr(), wsb.data_ptr(), wsb.numel(),
+                         x2=x2d.data_ptr() if cin2 else 0, W2=w2d.data_ptr() if cin2 else 0, gn=gnd,
+                         gn_stat=stat.data_ptr() if gn else 0, gn_gamma=gd.data_ptr() if gn else 0, gn_beta=bed.data_ptr() if gn else 0)
+        torch.cuda.synchronize()
+        assert torch.isnan(out[:, cout:]).all() if ldc > cout else True, "the pad columns of the output rows were written"
+        close(rows_to_5d(out, b, cout, f, H, W), ref, rel=3e-3, abs_frac=6e-3)
