@@ -15,7 +15,7 @@ events on the launch stream.  The two CFG halves of a step have identical inputs
 (RCDMs_pipeline.py:481-482), so conv_in, the first ResNet block and the first self-attention are evaluated once and
 stored for both (0.21 of the 11.044 TFLOP; exact — config.shared_cfg_prefix, --no-share-prefix for the A/B); `achieved`
 still prices the reference's full 11.044 TFLOP per call (`roofline.flops_skipped_tflop_per_launch` and `achieved_issued` give the issued-work view;
-the second entry of its breakdown is the 5/9 of the three Upsample3D convs that their exact four-phase 2x2 form does not multiply).  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
+the breakdown: the shared prefix; the 5/9 (four-phase form) or 27/36 (nine tap planes over the source pixels, round 6) of the Upsample3D convs' products that their exact forms do not multiply; the 20/36 the Winograd F(2x2, 3x3) form of the deep ResNet convolutions does not multiply).  `cpu_baseline`: the oracle restatement of the reference's CPU path (kind "port")
 timed on this box's host cores on a bounded sample (a few UNet calls of the 50), extrapolated to T calls."""
 import argparse
 import contextlib
@@ -43,6 +43,32 @@ def upsample_phase_tflop(plan):
         if m:
             n, h, w, ci, co = (int(v) for v in m.groups())
             t += 2.0 * n * 4 * h * w * 5 * ci * co / 1e12
+    return t
+
+
+def upsample_taps_tflop(plan):
+    """TFLOP per call the tap-plane upsampling convs (one N = 9 c GEMM over the source pixels + gather) leave out against
+    nearest-2x + conv3x3: 27 of the 36 products per source pixel."""
+    import re
+    t = 0.0
+    for tag in plan.tags:
+        m = re.match(r"upsample_gather (\d+)x(\d+)x(\d+) C=(\d+)", tag)
+        if m:
+            n, h, w, c = (int(v) for v in m.groups())
+            t += 2.0 * n * h * w * 27 * c * c / 1e12
+    return t
+
+
+def winograd_tflop(plan):
+    """TFLOP per call the Winograd F(2x2, 3x3) convs leave out against the nine taps: 20 of every 36 multiply-adds of the 3x3
+    part (the 1x1 shortcut entries are plain GEMMs: nothing left out)."""
+    import re
+    t = 0.0
+    for tag in plan.tags:
+        m = re.match(r"conv3x3_wino (\d+)x(\d+)x(\d+) (\d+)->(\d+)", tag)
+        if m:
+            n, h, w, ci, co = (int(v) for v in m.groups())
+            t += 2.0 * n * h * w * 9 * ci * co * (20.0 / 36.0) / 1e12
     return t
 
 
@@ -511,9 +537,13 @@ def main(argv=None):
         # ... and the 5/9 of every Upsample3D conv that the phase form (rcdm_conv3x3 upsample = 2) does not multiply: exact
         # algebra (a nearest-2x upsampled pixel grid holds every source pixel four times), read off the launch plan
         up2 = upsample_phase_tflop(loop.prog.plan) / S
-        roof["flops_skipped_tflop_per_launch"] = round((skipped + up2) * S, 4)
-        roof["flops_skipped_breakdown"] = {"shared_cfg_prefix": round(skipped * S, 4), "upsample_phase_form": round(up2 * S, 4)}
-        roof["achieved_issued"] = round(achieved * (1.0 - (skipped + up2) / (tf_call * (0.5 if a.cfg_split else 1.0))), 1)
+        up9 = upsample_taps_tflop(loop.prog.plan) / S      # (round 6: nine tap planes over the source pixels + gather, 27 of 36 left out)
+        # ... and the 20/36 of the ResNet 3x3 convolutions' multiply-adds the Winograd F(2x2, 3x3) form does not issue (round 6)
+        wino = winograd_tflop(loop.prog.plan) / S
+        roof["flops_skipped_tflop_per_launch"] = round((skipped + up2 + up9 + wino) * S, 4)
+        roof["flops_skipped_breakdown"] = {"shared_cfg_prefix": round(skipped * S, 4), "upsample_phase_form": round(up2 * S, 4),
+                                           "upsample_tap_planes": round(up9 * S, 4), "winograd_form": round(wino * S, 4)}
+        roof["achieved_issued"] = round(achieved * (1.0 - (skipped + up2 + up9 + wino) / (tf_call * (0.5 if a.cfg_split else 1.0))), 1)
 
     out = {
         "metric": "story-frames/sec (stage-2 UNet, 50-step DDIM, 512^2)", "value": round(value, 4),

@@ -312,6 +312,17 @@ int rcdm_conv3x3_wino_supported(const rcdm_conv3x3_desc* d);
 size_t rcdm_conv3x3_wino_workspace_bytes(const rcdm_conv3x3_desc* d);
 int rcdm_conv3x3_wino_plan_query(const rcdm_conv3x3_desc* d, int32_t* out8);   /* as rcdm_gemm_plan_query; variant 11, column tiles x entries */
 int rcdm_pack_conv3x3_wino(const float* w, int32_t c_out, int32_t c_in, void* dst, void* stream);
+/* Upsample3D.forward (resnet.py:60-79: F.interpolate(nearest, x2) + conv3x3) as ONE rcdm_gemm + this gather (round 6): on the
+ * upsampled grid output pixel (Y, X) = sum over the nine taps of w[ky][kx] . s((Y + ky - 1) >> 1, (X + kx - 1) >> 1), so every
+ * product is a tap's 1x1 image of a SOURCE pixel — nine products per source pixel and channel pair (the four-phase form of
+ * rcdm_conv3x3 upsample = 2 needs sixteen).  P = rcdm_gemm(source rows [n_img*h*w][c_in], W9) with W9 = f16 [9*c_out][c_in],
+ * row tap*c_out + c = weight[c][:][ky][kx] (tap = 3 ky + kx; the ordinary rounded weights, no sums), no bias: f16
+ * [n_img*h*w][ldp >= 9 c_out].  The gather adds, per output pixel of the (2h x 2w) image, the nine planes' values of the source
+ * pixels its taps land on (taps outside the upsampled image skipped = its zero padding) + bias[c_out] (may be NULL), fp32 sum,
+ * one rounding: out f16 [n_img*4*h*w][ldc].  Numerics: the nine products are rounded to f16 before the sum (one more rounding
+ * per term than the implicit GEMM's fp32 accumulation). */
+int rcdm_upsample_taps_gather(const void* P, int32_t ldp, int32_t n_img, int32_t h, int32_t w, int32_t c_out, const float* bias,
+                              void* out, int32_t ldc, void* stream);
 /* tuning / test switch: 1 = the batched GEMM of rcdm_conv3x3_wino leaves f16 slabs (half the bytes between it and the output
  * transform, whole-row stores; every transform-domain sum is rounded to f16 before A^T M A), 0 = fp32 slabs, -1 = default
  * (environment RCDM_WINO_SLAB16, else 1). */

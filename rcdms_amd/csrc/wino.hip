@@ -443,6 +443,63 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Upsample3D (nearest 2x, then conv3x3; resnet.py:60-79) as ONE plain GEMM + a gather.  On the upsampled grid output pixel
+// (Y, X) = sum over the nine taps of w[ky][kx] . s((Y + ky - 1) >> 1, (X + kx - 1) >> 1): every product is a tap's 1x1 image of
+// a SOURCE pixel, P[src pixel][tap * C_out + c] = x[src pixel][:] . w[c][:][tap] — nine products per source pixel and channel
+// pair where the four 2x2 phase convolutions (rcdm_conv3x3, upsample = 2) need sixteen and the literal form thirty-six.  The
+// products are one rcdm_gemm with N = 9 C_out over the source rows (no transform, the ordinary f16 weights, re-ordered);
+// this kernel sums, per output pixel, the nine planes' values of the source pixels its taps land on (taps outside the
+// upsampled image are skipped: its zero padding), adds the bias and rounds once.  One thread per (output pixel, 8 channels);
+// each P value is read by four neighbouring outputs (L2).
+struct UpGatherArgs {
+  const f16* P;
+  const float* bias;
+  f16* out;
+  int ldp, ldc, n_img, H, W, C;
+};
+__global__ __launch_bounds__(256) void upsample_gather_kernel(const UpGatherArgs p) {
+  const int nch = p.C >> 3;
+  const size_t total = (size_t)p.n_img * 4 * p.H * p.W * nch;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int o = (int)(idx / nch), c8 = (int)(idx - (size_t)o * nch);
+  const int W2 = 2 * p.W, H2 = 2 * p.H;
+  const int img = o / (H2 * W2), rem = o - img * (H2 * W2);
+  const int Y = rem / W2, X = rem - Y * W2;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, 0x7FFFFFFF, 0x00020000);
+  Pack16 v[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = Y + ky - 1, xx = X + kx - 1;
+      const bool ok = (unsigned)yy < (unsigned)H2 && (unsigned)xx < (unsigned)W2;
+      const unsigned row = (unsigned)(img * p.H * p.W + (yy >> 1) * p.W + (xx >> 1));
+      const unsigned off = ok ? (row * (unsigned)p.ldp + (unsigned)((ky * 3 + kx) * p.C + c8 * 8)) * 2u : 0x80000000u;
+      v[ky * 3 + kx].v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    }
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (p.bias) {
+    const f32x4 b0 = *(const f32x4*)(p.bias + c8 * 8), b1 = *(const f32x4*)(p.bias + c8 * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[e] = b0[e];
+      acc[4 + e] = b1[e];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += (float)v[k].e[e];
+  Pack16 q;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q.e[e] = (f16)acc[e];
+  *(uint4*)(p.out + (size_t)o * p.ldc + c8 * 8) = q.u;
+}
+
 int g_wino_cus = 0;
 int wino_cus() {
   if (g_wino_cus <= 0) {
@@ -536,6 +593,18 @@ int rcdm_conv3x3_wino_plan_query(const rcdm_conv3x3_desc* d, int32_t* out8) {
   out8[0] = 11; out8[1] = 160; out8[2] = 160; out8[3] = a.tilesM; out8[4] = a.tilesN * a.E; out8[5] = a.splits; out8[6] = 2;
   out8[7] = a.nk;
   return RCDM_OK;
+}
+
+int rcdm_upsample_taps_gather(const void* P, int32_t ldp, int32_t n_img, int32_t h, int32_t w, int32_t c_out, const float* bias,
+                              void* out, int32_t ldc, void* stream) {
+  if (!P || !out || n_img <= 0 || h <= 0 || w <= 0 || c_out <= 0) return RCDM_EINVAL;
+  if ((c_out & 7) || (ldp & 7) || (ldc & 7) || ldp < 9 * c_out || ldc < c_out) return RCDM_EINVAL;
+  if ((((uintptr_t)P | (uintptr_t)out | (uintptr_t)bias) & 15)) return RCDM_EINVAL;
+  if ((size_t)n_img * h * w * ldp * 2 >= (1ull << 31)) return RCDM_ESHAPE;   // 32-bit byte offsets into a 2-GB buffer resource
+  UpGatherArgs a{(const f16*)P, bias, (f16*)out, ldp, ldc, n_img, h, w, c_out};
+  const size_t total = (size_t)n_img * 4 * h * w * (c_out >> 3);
+  hipLaunchKernelGGL(upsample_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return rcdm_check_launch();
 }
 
 int rcdm_set_wino_slab_f16(int32_t on) {

@@ -172,8 +172,23 @@ def emit_conv3x3(plan, x, n_img, H, W, Wt, cin, cout, out, stride=1, up=0, bias=
     plan.n_launch += 2 if wsb else 1
 
 
+UP9_MIN_CHANNELS = 640   # the tap-plane form's GEMM has K = c: narrower convs keep the phase form
+
+
 def emit_upsample_conv(plan, pk, wkey, x, n_img, H, W, c, out, bias):
-    """Upsample3D.forward (src/models/resnet.py:60-79): F.interpolate(scale 2, nearest) + conv3x3, c -> c channels."""
+    """Upsample3D.forward (src/models/resnet.py:60-79): F.interpolate(scale 2, nearest) + conv3x3, c -> c channels.
+    Three exact forms, by cost: nine tap planes over the SOURCE pixels as one GEMM (N = 9 c) + a gather (9 products per source
+    pixel), four 2x2 phase convolutions (16), the nine-tap implicit GEMM over the upsampled grid (36)."""
+    if SW.UP9 and c >= UP9_MIN_CHANNELS and c % 8 == 0 and n_img * H * W * 9 * c * 2 < (1 << 31):
+        P = plan.rows("up_taps", n_img * H * W, 9 * c)
+        emit_gemm(plan, x, pk.conv3x3_taps(wkey), 9 * c, c, P)
+
+        def op():
+            hip.upsample_taps_gather(P.ptr, P.ld, n_img, H, W, c, bias.data_ptr() if bias is not None else 0, out.ptr, out.ld)
+        plan.add(op, f"upsample_gather {n_img}x{H}x{W} C={c}")
+        plan.keep += [bias]
+        plan.n_launch += 1
+        return
     d2 = hip.ConvDesc(n_img, H, W, c, c, 1, 2, x.ld, out.ld, 0, hip.EPI_BIAS if bias is not None else 0, 1, 0, 1.0, 0, 0, 0)
     if SW.UP2 and hip.conv3x3_up2_supported(d2):
         emit_conv3x3(plan, x, n_img, H, W, pk.conv3x3_up2(wkey), c, c, out, up=2, bias=bias)

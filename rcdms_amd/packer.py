@@ -73,6 +73,17 @@ class Packer:
         self._tmp.append(w)
         return dst
 
+    def conv3x3_taps(self, key):
+        """Tap-plane weights of an Upsample3D conv (rcdm_gemm + rcdm_upsample_taps_gather): f16 [9 * cout][cin], row
+        tap * cout + c = weight[c][:][ky][kx]."""
+        w = self.f32(key)
+        cout, cin = w.shape[0], w.shape[1]
+        src = w.permute(2, 3, 0, 1).reshape(9 * cout, cin).contiguous()
+        dst = torch.empty(9 * cout, cin, dtype=torch.float16, device=self.device)
+        hip.pack_f16(src.data_ptr(), dst.data_ptr(), src.numel())
+        self._tmp += [w, src]
+        return dst
+
     def conv3x3_up2(self, key):
         """Phase weights of an Upsample3D conv (rcdm_conv3x3 with upsample = 2): f16 [4][cout][4 * cin]."""
         w = self.f32(key)

@@ -21,9 +21,10 @@ RANK1_CTX = _on("RCDM_RANK1_CTX")    # 0: cross-attention evaluated in full even
 # latent sides (comma list) whose stride-1 3x3 convolutions of the ResNet blocks take the Winograd F(2x2, 3x3) form (rcdm_conv3x3_wino,
 # with the GroupNorm apply + SiLU in its input transform) instead of the nine-tap implicit GEMM; "0" = none (resnet.py:182-212)
 WINO = tuple(int(v) for v in os.environ.get("RCDM_WINO", "32,16,8").split(",") if v.strip() and int(v) > 0)
+UP9 = _on("RCDM_UP9")                # 0: Upsample3D as four 2x2 phase convolutions (RCDM_UP2) instead of one 9-tap-plane GEMM + gather (resnet.py:60-79)
 CHAIN_MIN_ROWS = os.environ.get("RCDM_CHAIN_MIN_ROWS")   # token rows from which the chains are used (default: 3/4 of a chip of 160-row blocks)
 
 TABLE = {
     "RCDM_SC_FOLD": SC_FOLD, "RCDM_UP2": UP2, "RCDM_GN_PRESTAT": GN_PRESTAT, "RCDM_LNX": LNX, "RCDM_FFZ": FFZ,
-    "RCDM_FF_FUSE": FF_FUSE, "RCDM_ROWCHAIN": ROW_CHAIN, "RCDM_RANK1_CTX": RANK1_CTX, "RCDM_WINO": WINO, "RCDM_CHAIN_MIN_ROWS": CHAIN_MIN_ROWS,
+    "RCDM_FF_FUSE": FF_FUSE, "RCDM_ROWCHAIN": ROW_CHAIN, "RCDM_RANK1_CTX": RANK1_CTX, "RCDM_WINO": WINO, "RCDM_UP9": UP9, "RCDM_CHAIN_MIN_ROWS": CHAIN_MIN_ROWS,
 }

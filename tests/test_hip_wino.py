@@ -221,3 +221,43 @@ def test_conv3x3_wino_random_shapes(hiplib):
         torch.cuda.synchronize()
         assert torch.isnan(out[:, cout:]).all() if ldc > cout else True, "the pad columns of the output rows were written"
         close(rows_to_5d(out, b, cout, f, H, W), ref, rel=3e-3, abs_frac=6e-3)
+
+
+@pytest.mark.parametrize("n_img,H,W,c", [(3, 4, 6, 64), (10, 8, 8, 640), (10, 16, 16, 1280)])
+def test_upsample_tap_planes(hiplib, n_img, H, W, c):
+    """Upsample3D (resnet.py:60-79) as one GEMM over the SOURCE pixels with the nine taps' weights stacked (N = 9 c) + the gather
+    rcdm_upsample_taps_gather, against F.interpolate(nearest, x2) + conv3x3 in fp32 and next to the four-phase form."""
+    from rcdms_amd import hip
+    g = torch.Generator().manual_seed(40 + c + H)
+    x = h16(torch.randn(1, c, n_img, H, W, generator=g))
+    w = h16(torch.randn(c, c, 3, 3, generator=g) * (9 * c) ** -0.5)
+    bias = torch.randn(c, generator=g)
+    ref = O.conv_frames(F.interpolate(x, scale_factor=[1.0, 2.0, 2.0], mode="nearest"), w, bias, stride=1, padding=1)
+    lda = c + 8
+    xd = rows_from_5d(x, lda)
+    W9 = w.permute(2, 3, 0, 1).reshape(9 * c, c).half().to(DEV).contiguous()
+    M = n_img * H * W
+    ldp = 9 * c + 8
+    P = torch.full((M, ldp), float("nan"), dtype=torch.float16, device=DEV)
+    d = hip.GemmDesc(M, 9 * c, c, lda, ldp, 0, 0, 1, 0, 1.0, 0, 0)
+    wsb = ws(hip.gemm_workspace_bytes(d))
+    hip.gemm(d, xd.data_ptr(), W9.data_ptr(), 0, 0, 0, P.data_ptr(), wsb.data_ptr(), wsb.numel())
+    out = torch.full((4 * M, c), float("nan"), dtype=torch.float16, device=DEV)
+    bd = bias.to(DEV)
+    hip.upsample_taps_gather(P.data_ptr(), ldp, n_img, H, W, c, bd.data_ptr(), out.data_ptr(), c)
+    torch.cuda.synchronize()
+    got = rows_to_5d(out, 1, c, n_img, 2 * H, 2 * W)
+    close(got, ref)
+    if c % 64 == 0 and c >= 640:
+        d2 = hip.ConvDesc(n_img, H, W, c, c, 1, 2, lda, c, 0, hip.EPI_BIAS, 1, 0, 1.0, 0)
+        if hip.conv3x3_up2_supported(d2):
+            wp2 = torch.empty(4, c, 4 * c, dtype=torch.float16, device=DEV)
+            w32 = w.to(DEV)
+            hip.pack_conv3x3_up2(w32.data_ptr(), c, c, wp2.data_ptr())
+            out2 = torch.full((4 * M, c), float("nan"), dtype=torch.float16, device=DEV)
+            w2 = ws(hip.conv3x3_workspace_bytes(d2))
+            hip.conv3x3(d2, xd.data_ptr(), wp2.data_ptr(), bd.data_ptr(), 0, 0, out2.data_ptr(), w2.data_ptr(), w2.numel())
+            torch.cuda.synchronize()
+            e9, e4 = _rel_rms(got, ref), _rel_rms(rows_to_5d(out2, 1, c, n_img, 2 * H, 2 * W), ref)
+            print(f"rel-RMS vs fp32: tap planes {e9:.3e}, four phases {e4:.3e}")
+            assert e9 <= 3.0 * e4 + 1e-4
