@@ -149,8 +149,9 @@ int rcdm_set_igemm_variant(int32_t variant);  /* 6 / 7 / 8: ping-pong kernel at 
 /* Tuning switch: 0 = the shape heuristic never picks the 8-wave ping-pong kernel (igemm8.hip), 1 = it may
  * (default; environment RCDM_PP=0 sets the initial state).  Used for same-process A/B timing. */
 int rcdm_set_igemm_pingpong(int32_t on);
-/* Tuning / test switch: 1 = split-K launches of the 160x160 kernel leave f16 slabs (half the bytes to and from the reduce
- * pass; one extra f16 rounding per partial sum), 0 = fp32 slabs, -1 = default (environment RCDM_SLAB16, else 0). */
+/* Tuning / test switch: 1 = split-K launches of the 160x160 and the LDS-DMA tile kernels leave f16 slabs (half the bytes to and
+ * from the reduce pass; one extra f16 rounding per partial sum; not the GEGLU projections, not the ping-pong kernel), 0 = fp32
+ * slabs, -1 = default (environment RCDM_SLAB16, else 1: measured -0.11 ms per step, whole-UNet error unchanged). */
 int rcdm_set_splitk_slab_f16(int32_t on);
 /* debug: when non-NULL, every igemm block writes 4 int64 {start, end (s_memtime ticks), ticks spent in epilogues,
  * k-steps done} at trace[(blockIdx.y*gridDim.x + blockIdx.x)*4]; NULL (default) disables it. */

@@ -62,7 +62,7 @@ struct IgemmArgs {
   const f16* A2;
   int lda2, Cin2;
   int nk1 = 0x7fffffff;         // (default member initialiser: `IgemmArgs a{}` must not switch the second input on)
-  // split-K slabs as f16 (round 6; the 160x160 kernel's split launches): the partial sums travel to the reduce pass through the
+  // split-K slabs as f16 (round 6; the split launches of the 160x160 kernel and of the LDS-DMA tile kernels): the partial sums travel to the reduce pass through the
   // staged, coalesced f16 epilogue — half the slab bytes each way — at one extra f16 rounding per partial.  0 = fp32 slabs.
   int slab16 = 0;
 };

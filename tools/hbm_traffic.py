@@ -4,7 +4,7 @@ kernels of the denoising step, with the gfx950 correction of MI355X_MICROARCH.md
 requests as 64 B for wide coalesced reads -> doubled.  usage: hbm_traffic.py <dir> <n_steps>"""
 import glob, json, os, sqlite3, sys
 d, steps = sys.argv[1], float(sys.argv[2])
-STEP_KERNELS = ("igemm", "row_chain", "splitk_reduce", "flash_attn", "xattn_kernel", "temporal_attn", "layernorm", "gn_", "small_linear",
+STEP_KERNELS = ("igemm", "wino_", "upsample_gather", "row_chain", "splitk_reduce", "flash_attn", "xattn_kernel", "temporal_attn", "layernorm", "gn_", "small_linear",
                 "load_table_row",
                 "timestep_embed", "assemble_input", "cfg_ddim", "load_timestep", "advance_step")
 res = {}
