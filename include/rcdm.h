@@ -286,6 +286,10 @@ int rcdm_groupnorm_stats_prestat(const rcdm_groupnorm_desc* d, float* stat, void
  * Used behind rcdm_conv3x3_wino(gn_out, ...), whose output transform leaves one partial per (sample, group, 2x2 tile). */
 int rcdm_groupnorm_finalize(int32_t samples, int32_t groups, int32_t splits, float eps, const float* partial, float* stat,
                             void* stream);
+/* the apply launch alone: y = (x - mean) rstd gamma + beta (+ SiLU) with (mean, rstd) = stat[sample][group] already final
+ * (rcdm_groupnorm_finalize / rcdm_groupnorm_stats) — the third launch of the three-launch form. */
+int rcdm_groupnorm_apply(const rcdm_groupnorm_desc* d, const void* x, const float* stat, const float* gamma, const float* beta,
+                         void* y, void* stream);
 
 /* conv3x3, stride 1, padding 1, as Winograd F(2x2, 3x3) (wino.hip; round 6): the same operation as rcdm_conv3x3 /
  *   rcdm_conv3x3_add1x1 — ResnetBlock3D's conv1 / conv2 (+ conv_shortcut), resnet.py:188,205-212 — with 4/9 of the

@@ -758,6 +758,24 @@ int rcdm_groupnorm_stats_prestat(const rcdm_groupnorm_desc* d, float* stat, void
   return rcdm_check_launch();
 }
 
+int rcdm_groupnorm_apply(const rcdm_groupnorm_desc* d, const void* x, const float* stat, const float* gamma, const float* beta,
+                         void* y, void* stream_) {
+  if (!d || !x || !stat || !gamma || !beta || !y) return RCDM_EINVAL;
+  GnArgs a{};
+  int rc = gn_plan(d, a);
+  if (rc) return rc;
+  const int threads = a.CH * a.RPB;
+  if (threads > 1024) return RCDM_ESHAPE;
+  a.x = (const f16*)x; a.y = (f16*)y; a.gamma = gamma; a.beta = beta;
+  a.stat = const_cast<float*>(stat);
+  int bps = (a.P + a.RPB * 8 - 1) / (a.RPB * 8);  // ~8 rows per thread (as gn_finalize_apply)
+  const int cap = (2048 + a.samples - 1) / a.samples;
+  if (bps > cap) bps = cap;
+  if (bps < 1) bps = 1;
+  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(bps, a.samples), dim3(threads), 0, (hipStream_t)stream_, a);
+  return rcdm_check_launch();
+}
+
 int rcdm_groupnorm_finalize(int32_t samples, int32_t groups, int32_t splits, float eps, const float* partial, float* stat,
                             void* stream_) {
   if (!partial || !stat || samples <= 0 || groups <= 0 || splits <= 0) return RCDM_EINVAL;

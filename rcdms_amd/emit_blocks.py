@@ -43,10 +43,10 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
         gn2 = emit_groupnorm_stats(plan, h1, g.b, g.f * g.hw, w.g2, w.b2, eps, groups)
         if w.shortcut is not None:   # conv_shortcut(x) as four parity GEMMs of conv2's batched launch
             emit_conv3x3_wino(plan, h1, g.n_img, g.H, g.W, w.wino2, w.cout, w.cout, out, bias=w.cb2sc, scale=out_scale, gn=gn2,
-                              x2=x, W2=w.shortcut)
+                              x2=x, W2=w.shortcut, gn_out=out_gn, gn_out_apply=True)
         else:
             emit_conv3x3_wino(plan, h1, g.n_img, g.H, g.W, w.wino2, w.cout, w.cout, out, bias=w.cb2, residual=x, scale=out_scale,
-                              gn=gn2)
+                              gn=gn2, gn_out=out_gn, gn_out_apply=True)
         return
     fold_sc = w.conv2sc is not None
     assert not fold_sc or x.C == w.cin

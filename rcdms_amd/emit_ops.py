@@ -201,19 +201,24 @@ def emit_groupnorm(plan, x, samples, rows_per_sample, gamma, beta, eps, silu, ou
     ws = plan.scratch("gn_ws", hip.groupnorm_workspace_bytes(d))
     rdy = getattr(plan, "gn_ready", None)
     plan.gn_ready = None
-    pre = (rdy is not None and rdy["n_ops"] == len(plan.ops) and rdy["key"] == x.ptr_key() and rdy["M"] == x.M and
-           rdy["C"] == x.C and rdy["gn"] == (samples, rows_per_sample, groups) and rdy.get("tiles") is None and
-           hip.groupnorm_prestat_ok(d))
-    assert rdy is None or rdy["n_ops"] != len(plan.ops) or pre, "a producer left GroupNorm statistics that nobody consumes"
+    match = (rdy is not None and rdy["n_ops"] == len(plan.ops) and rdy["key"] == x.ptr_key() and rdy["M"] == x.M and
+             rdy["C"] == x.C and rdy["gn"] == (samples, rows_per_sample, groups))
+    tiles = match and rdy.get("tiles") is not None     # per-tile partials of a Winograd conv's output transform (its own geometry)
+    pre = match and not tiles and hip.groupnorm_prestat_ok(d)
+    assert rdy is None or rdy["n_ops"] != len(plan.ops) or pre or tiles, "a producer left GroupNorm statistics that nobody consumes"
+    stat = plan.scratch("gn_stat", samples * groups * 2 * 4) if tiles else None
 
     def op():
-        if pre:   # the partial statistics are in ws already (the producer's reduce pass)
+        if tiles:   # finalize the producer's per-tile partials, then the apply launch alone
+            hip.groupnorm_finalize(samples, groups, rdy["tiles"][1], eps, rdy["tiles"][0].ptr, stat.ptr)
+            hip.groupnorm_apply(d, x.ptr, stat.ptr, gamma.data_ptr(), beta.data_ptr(), out.ptr)
+        elif pre:   # the partial statistics are in ws already (the producer's reduce pass)
             hip.groupnorm_silu_prestat(d, x.ptr, gamma.data_ptr(), beta.data_ptr(), out.ptr, ws.ptr, ws.nbytes)
         else:
             hip.groupnorm_silu(d, x.ptr, gamma.data_ptr(), beta.data_ptr(), out.ptr, ws.ptr, ws.nbytes)
-    plan.add(op, f"groupnorm S={samples} R={rows_per_sample} C={x.C} silu={int(silu)}" + (" prestat" if pre else ""))
+    plan.add(op, f"groupnorm S={samples} R={rows_per_sample} C={x.C} silu={int(silu)}" + (" prestat" if pre or tiles else ""))
     plan.keep += [gamma, beta]
-    plan.n_launch += 2 if pre else 3
+    plan.n_launch += 2 if (pre or tiles) else 3
 
 
 def emit_groupnorm_stats(plan, x, samples, rows_per_sample, gamma, beta, eps, groups=32):
@@ -251,12 +256,13 @@ def conv3x3_wino_ok(n_img, H, W, cin, cout, cin2=0):
 
 
 def emit_conv3x3_wino(plan, x, n_img, H, W, U, cin, cout, out, bias=None, rowvec=None, residual=None, scale=1.0, split_k=0,
-                      gn=None, silu=True, x2=None, W2=None, gn_out=None):
+                      gn=None, silu=True, x2=None, W2=None, gn_out=None, gn_out_apply=False):
     """Stride-1 conv3x3 in the Winograd F(2x2, 3x3) form (rcdm_conv3x3_wino; ResnetBlock3D conv1 / conv2, resnet.py:188,205-212).
     gn = emit_groupnorm_stats(...) of the norm in front of the conv: x holds its RAW input and the input transform applies the
     normalisation (+ SiLU) on the way.  x2 / W2: the second input and its plain f16 [cout][x2.C] 1x1 weight (conv_shortcut).
     gn_out = (samples, rows_per_sample, groups) of the GroupNorm whose STATISTICS-ONLY launch (emit_groupnorm_stats) is the very
-    next op on `out`: the output transform leaves per-tile partials and that launch becomes the finalize alone."""
+    next op on `out`: the output transform leaves per-tile partials and that launch becomes the finalize alone.  gn_out_apply:
+    the next op is the norm's full form (emit_groupnorm: finalize + apply then) — only worth it where that norm has three launches."""
     epi = 0
     if bias is not None:
         epi |= hip.EPI_BIAS
@@ -278,7 +284,10 @@ def emit_conv3x3_wino(plan, x, n_img, H, W, U, cin, cout, out, bias=None, rowvec
     if gn_out is not None and SW.GN_PRESTAT and gn_out[0] * gn_out[1] == out.M and gn_out[1] % (H * W) == 0 and cout % gn_out[2] == 0 \
             and cout * 8 <= 65536 and gn_out[2] <= 64:
         god = hip.GroupNormDesc(gn_out[0], gn_out[1], cout, gn_out[2], out.ld, out.ld, 1e-5, 0)
-        gop = plan.scratch("gn_tile_part", gn_out[0] * gn_out[2] * (gn_out[1] // 4) * 3 * 4)
+        if gn_out_apply and not hip.groupnorm_prestat_ok(god):
+            god = None     # the consumer is a single-launch norm (<= 512 rows per sample): nothing to save
+        else:
+            gop = plan.scratch("gn_tile_part", gn_out[0] * gn_out[2] * (gn_out[1] // 4) * 3 * 4)
     bptr = bias.data_ptr() if bias is not None else 0
     rv_t, rv_off = (rowvec[0], rowvec[1]) if rowvec else (None, 0)
 

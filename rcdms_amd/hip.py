@@ -163,6 +163,7 @@ SYMBOLS = {
     "rcdm_conv3x3_wino": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                     C.POINTER(GroupNormDesc), _P, _P]),
     "rcdm_groupnorm_finalize": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P]),
+    "rcdm_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P]),
     "rcdm_pack_geglu_rows": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
     "rcdm_graph_begin_capture": (C.c_int, [_P]),
     "rcdm_graph_end_capture": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
@@ -566,6 +567,11 @@ def conv3x3_wino(desc, x, U, bias, rowvec, residual, out, ws_ptr, ws_bytes, x2=0
                                     bias, rowvec, residual, out, ws_ptr, ws_bytes, C.byref(gn_out) if gn_out is not None else None,
                                     gn_out_partial, stream_ptr() if stream is None else stream),
            "rcdm_conv3x3_wino")
+
+
+def groupnorm_apply(desc, x, stat, gamma, beta, y, stream=None):
+    _check(load().rcdm_groupnorm_apply(C.byref(desc), x, stat, gamma, beta, y, stream_ptr() if stream is None else stream),
+           "rcdm_groupnorm_apply")
 
 
 def groupnorm_finalize(samples, groups, splits, eps, partial, stat, stream=None):

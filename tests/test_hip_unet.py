@@ -151,8 +151,10 @@ def test_full_unet_plan_takes_the_winograd_form(full_unet):
     assert len(wino) == 30, len(wino)          # 16 conv1 (down_blocks.1.resnets.0 has 320 input channels) + 14 conv2
     assert not any("x64x64 " in t for t in wino)
     assert all(" gn" in t for t in wino)
-    # conv1 -> norm2 hand-off: the output transform leaves the statistics wherever conv2 is a Winograd conv too
-    assert sum(" gnstat" in t for t in wino) == 13
+    # statistics hand-offs out of the output transform: conv1 -> norm2 wherever conv2 is a Winograd conv too (13), and conv2 ->
+    # the per-frame norm of the transformer behind it where that norm has three launches (the five ResNet blocks of the 32x32 level)
+    conv1 = [t for t in wino if " epi=3 " in t]
+    assert sum(" gnstat" in t for t in conv1) == 13 and sum(" gnstat" in t for t in wino) == 18
     nine_tap_low = [t for t in tags if t.startswith("conv3x3 ") and " s=1 up=0 " in t and "x64x64 " not in t]
     assert len(nine_tap_low) == 4, nine_tap_low     # conv1 of the 320 -> 640 block + the three 8x8 conv2 with a shortcut
 

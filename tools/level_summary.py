@@ -4,7 +4,7 @@ tools/opprof.py table (run it with --top 1000 so that every op is listed).   usa
 import re
 import sys
 
-KINDS = ("gemm_ln", "gemm", "conv3x3_wino", "conv3x3", "rowchain", "flash_attn", "xattn", "temporal_attn", "groupnorm_stats", "groupnorm",
+KINDS = ("gemm_ln", "gemm", "conv3x3_wino", "conv3x3", "upsample_gather", "rowchain", "flash_attn", "xattn", "temporal_attn", "groupnorm_stats", "groupnorm",
          "layernorm", "ff_fused")
 
 
@@ -13,6 +13,9 @@ def level(tag):
     kind = tag.split()[0]
     if kind in ("gemm", "gemm_ln", "rowchain", "layernorm", "ff_fused"):
         M = int(kv["M"])
+    elif kind == "upsample_gather":
+        n, H, W = map(int, re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
+        M = n * H * W * 4
     elif kind == "conv3x3_wino":
         n, H, W = map(int, re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
         M = n * H * W
