@@ -65,9 +65,9 @@ WINO_SHORTCUT_MIN_SIDE = 16   # below: a conv2 that carries a conv_shortcut keep
 
 
 def wino_level(geo, cin, cout):
-    """(conv1, conv2): which 3x3 convolutions of a ResNet block of this geometry take the Winograd form (switches.WINO: the latent
-    sides it is used at — where the nine-tap implicit GEMM is a split-K latency chain, not a stream)."""
-    if not (geo.H == geo.W and geo.H in SW.WINO):
+    """(conv1, conv2): which 3x3 convolutions of a ResNet block of this geometry take the Winograd form (switches.wino_side: the
+    levels it is used at — sides <= 32, where the nine-tap implicit GEMM is a split-K latency chain, not a stream)."""
+    if not SW.wino_side(geo.H, geo.W):
         return (False, False)
     u1 = min(cin, cout) >= WINO_MIN_CHANNELS and conv3x3_wino_ok(geo.n_img, geo.H, geo.W, cin, cout)
     cin2 = cin if cin != cout else 0

@@ -18,13 +18,26 @@ FFZ = _on("RCDM_FFZ")                # 0: ff.net.2 and proj_out as two GEMMs ins
 FF_FUSE = _on("RCDM_FF_FUSE")        # 0: LayerNorm -> GEGLU -> ff.net.2 as three launches instead of rcdm_ff_fused
 ROW_CHAIN = _on("RCDM_ROWCHAIN")     # 0: separate launches instead of the row-stationary chains of the 64x64 level
 RANK1_CTX = _on("RCDM_RANK1_CTX")    # 0: cross-attention evaluated in full even for images whose context rows are all equal
-# latent sides (comma list) whose stride-1 3x3 convolutions of the ResNet blocks take the Winograd F(2x2, 3x3) form (rcdm_conv3x3_wino,
-# with the GroupNorm apply + SiLU in its input transform) instead of the nine-tap implicit GEMM; "0" = none (resnet.py:182-212)
-WINO = tuple(int(v) for v in os.environ.get("RCDM_WINO", "32,16,8").split(",") if v.strip() and int(v) > 0)
+# which latent sizes run the stride-1 3x3 convolutions of their ResNet blocks (>= 640 channels) in the Winograd F(2x2, 3x3) form
+# (rcdm_conv3x3_wino, with the GroupNorm apply + SiLU in its input transform) instead of the nine-tap implicit GEMM
+# (resnet.py:182-212): "le<N>" = every level whose (even) sides are in [8, N], a comma list = exactly those sides, "0" = none
+_w = os.environ.get("RCDM_WINO", "le32").strip()
+WINO_MAX_SIDE = int(_w[2:]) if _w.startswith("le") else 0
+WINO_MIN_SIDE = 8     # (below: 4 tiles per image, unmeasured)
+WINO = tuple(int(v) for v in _w.split(",") if v.strip().isdigit() and int(v) > 0) if not _w.startswith("le") else ()
+
+
+def wino_side(H, W):
+    """Whether a level of H x W latents is one of the Winograd levels."""
+    if H % 2 or W % 2:
+        return False
+    return (min(H, W) >= WINO_MIN_SIDE and max(H, W) <= WINO_MAX_SIDE) if WINO_MAX_SIDE else (H == W and H in WINO)
+
+
 UP9 = _on("RCDM_UP9")                # 0: Upsample3D as four 2x2 phase convolutions (RCDM_UP2) instead of one 9-tap-plane GEMM + gather (resnet.py:60-79)
 CHAIN_MIN_ROWS = os.environ.get("RCDM_CHAIN_MIN_ROWS")   # token rows from which the chains are used (default: 3/4 of a chip of 160-row blocks)
 
 TABLE = {
     "RCDM_SC_FOLD": SC_FOLD, "RCDM_UP2": UP2, "RCDM_GN_PRESTAT": GN_PRESTAT, "RCDM_LNX": LNX, "RCDM_FFZ": FFZ,
-    "RCDM_FF_FUSE": FF_FUSE, "RCDM_ROWCHAIN": ROW_CHAIN, "RCDM_RANK1_CTX": RANK1_CTX, "RCDM_WINO": WINO, "RCDM_UP9": UP9, "RCDM_CHAIN_MIN_ROWS": CHAIN_MIN_ROWS,
+    "RCDM_FF_FUSE": FF_FUSE, "RCDM_ROWCHAIN": ROW_CHAIN, "RCDM_RANK1_CTX": RANK1_CTX, "RCDM_WINO": _w, "RCDM_UP9": UP9, "RCDM_CHAIN_MIN_ROWS": CHAIN_MIN_ROWS,
 }

@@ -139,11 +139,11 @@ def test_full_unet_plan_folds_the_resnet_shortcuts(full_unet):
 
 def test_full_unet_plan_takes_the_winograd_form(full_unet):
     """Round 6: at 64x64 latents the ResNet blocks of the 32x32 / 16x16 / 8x8 levels (>= 640 channels) run their stride-1 3x3
-    convolutions as rcdm_conv3x3_wino (switches.WINO) — 17 blocks, 31 launches: every conv1 with >= 640 input channels, every
+    convolutions as rcdm_conv3x3_wino (switches.wino_side) — 17 blocks, 31 launches: every conv1 with >= 640 input channels, every
     conv2 except the three that carry a conv_shortcut at the 8x8 level — each fed by a statistics-only GroupNorm (the apply rides
     in the input transform), and no Winograd launch appears at the 64x64 level.  (The goldens above run through exactly this plan.)"""
     from rcdms_amd import switches as SW
-    if tuple(SW.WINO) != (32, 16, 8):
+    if SW.WINO_MAX_SIDE != 32:
         pytest.skip("RCDM_WINO overridden")
     full_unet(torch.zeros(2, 9, 5, 64, 64, device=DEV), torch.tensor(981), torch.zeros(10, 85, 768, device=DEV), return_dict=False)
     tags = full_unet.program(2, 5, 64, 64, 85).plan.tags
