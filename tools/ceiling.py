@@ -50,6 +50,9 @@ def level_of(tag):
     rows = None
     if kind in ("gemm", "rowchain", "ff_fused", "layernorm"):
         rows = kv.get("M")
+    elif kind == "upsample_gather":
+        n, H, W = (float(v) for v in re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
+        rows = n * H * W * 4
     elif kind == "conv3x3_wino":
         n, H, W = (float(v) for v in re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
         rows = n * H * W
