@@ -328,6 +328,12 @@ int rcdm_pack_conv3x3_wino(const float* w, int32_t c_out, int32_t c_in, void* ds
  * per term than the implicit GEMM's fp32 accumulation). */
 int rcdm_upsample_taps_gather(const void* P, int32_t ldp, int32_t n_img, int32_t h, int32_t w, int32_t c_out, const float* bias,
                               void* out, int32_t ldc, void* stream);
+/* the same gather with upsample = 0: a plain stride-1, padding-1 conv3x3 as rcdm_gemm (N = 9 c_out tap planes over its own
+ * pixels) + gather — no multiply saved, but a conv with very few output channels (unet.py:457 conv_out: 320 -> 4) becomes a
+ * plain GEMM whose N is 9x wider than the conv's, instead of an implicit GEMM that pads 4 channels to a 64-wide tile.
+ * upsample = 1 is rcdm_upsample_taps_gather. */
+int rcdm_conv_taps_gather(const void* P, int32_t ldp, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t upsample,
+                          const float* bias, void* out, int32_t ldc, void* stream);
 /* tuning / test switch: 1 = the batched GEMM of rcdm_conv3x3_wino leaves f16 slabs (half the bytes between it and the output
  * transform, whole-row stores; every transform-domain sum is rounded to f16 before A^T M A), 0 = fp32 slabs, -1 = default
  * (environment RCDM_WINO_SLAB16, else 1). */

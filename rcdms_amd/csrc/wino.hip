@@ -11,12 +11,19 @@
 // Three launches: (1) wino_in_kernel — V[pos][tile][c] = (B^T d B)[pos], fp32 arithmetic on the f16 pixels, ONE rounding to
 // f16; optionally the GroupNorm apply + SiLU of the norm in front of the conv (resnet.py:185-186,202) on the way in, so the
 // normalised tensor is never written; (2) wino_gemm_kernel — the 160x160-tile LDS-DMA loop of igemm16.hip over
-// E = 16 (+ 4) batch entries x split-K slices, fp32 results to slabs [entry][split][tile][N]: entry e < 16 is
-// V[e] (T x K) against U[e] (N x K); entries 16 + 2a + b (only with a second input) are the 1x1 convolution of the pixels
-// (2ty + a, 2tx + b) of in2 against W2 — plain GEMM rows picked by parity, no transform; (3) wino_out_kernel — the fixed-order
-// sum of a tile's slabs, A^T M A in fp32, the 1x1 terms, bias / per-sample row vector / residual / scale, one rounding to f16.
+// E = 16 (+ 4) batch entries x split-K slices x tiles, dealt to the XCDs as contiguous runs (whole positions per L2), results
+// to slabs [entry][split][tile][N] — f16 through the staged epilogue by default (rcdm_set_wino_slab_f16), fp32 otherwise:
+// entry e < 16 is V[e] (T x K) against U[e] (N x K); entries 16 + 2a + b (only with a second input) are the 1x1 convolution
+// of the pixels (2ty + a, 2tx + b) of in2 against W2 — plain GEMM rows picked by parity, no transform; (3) wino_out_kernel —
+// the fixed-order sum of a tile's slabs, A^T M A in fp32, the 1x1 terms, bias / per-sample row vector / residual / scale, one
+// rounding to f16, and optionally the per-tile partial statistics of the GroupNorm that reads the output next.
 // Numerics: the products see f16(B^T d B) and f16(G g G^T) instead of f16 pixels and f16 weights: |B^T d B| <= 4 max|d|
-// (typically 2x), so the operand rounding noise is about twice the direct form's; everything after the MFMAs is fp32.
+// (typically 2x), so the operand rounding noise is about twice the direct form's; with f16 slabs every position sum is
+// rounded once more before the output transform; both transforms and the accumulation are fp32.  DESIGN.md section 4g.
+//
+// Also here, because they are the same kind of algebra on the 3x3 convolution: upsample_gather_kernel
+// (rcdm_conv_taps_gather / rcdm_upsample_taps_gather) — Upsample3D (resnet.py:60-79) and conv_out (unet.py:457) as ONE plain
+// GEMM over nine stacked tap planes + a gather.
 #include "common.h"
 #include "igemm_args.h"
 #include "pp_sync.h"
@@ -457,14 +464,15 @@ struct UpGatherArgs {
   const float* bias;
   f16* out;
   int ldp, ldc, n_img, H, W, C;
+  int up;   // 1: the taps index the nearest-2x upsampled image (source pixel = tap position >> 1); 0: a plain stride-1 conv3x3
 };
 __global__ __launch_bounds__(256) void upsample_gather_kernel(const UpGatherArgs p) {
   const int nch = p.C >> 3;
-  const size_t total = (size_t)p.n_img * 4 * p.H * p.W * nch;
+  const size_t total = ((size_t)p.n_img * p.H * p.W << (2 * p.up)) * nch;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int o = (int)(idx / nch), c8 = (int)(idx - (size_t)o * nch);
-  const int W2 = 2 * p.W, H2 = 2 * p.H;
+  const int W2 = p.W << p.up, H2 = p.H << p.up;
   const int img = o / (H2 * W2), rem = o - img * (H2 * W2);
   const int Y = rem / W2, X = rem - Y * W2;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, 0x7FFFFFFF, 0x00020000);
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(256) void upsample_gather_kernel(const UpGatherArgs
     for (int kx = 0; kx < 3; ++kx) {
       const int yy = Y + ky - 1, xx = X + kx - 1;
       const bool ok = (unsigned)yy < (unsigned)H2 && (unsigned)xx < (unsigned)W2;
-      const unsigned row = (unsigned)(img * p.H * p.W + (yy >> 1) * p.W + (xx >> 1));
+      const unsigned row = (unsigned)(img * p.H * p.W + (yy >> p.up) * p.W + (xx >> p.up));
       const unsigned off = ok ? (row * (unsigned)p.ldp + (unsigned)((ky * 3 + kx) * p.C + c8 * 8)) * 2u : 0x80000000u;
       v[ky * 3 + kx].v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
     }
@@ -595,16 +603,21 @@ int rcdm_conv3x3_wino_plan_query(const rcdm_conv3x3_desc* d, int32_t* out8) {
   return RCDM_OK;
 }
 
-int rcdm_upsample_taps_gather(const void* P, int32_t ldp, int32_t n_img, int32_t h, int32_t w, int32_t c_out, const float* bias,
-                              void* out, int32_t ldc, void* stream) {
-  if (!P || !out || n_img <= 0 || h <= 0 || w <= 0 || c_out <= 0) return RCDM_EINVAL;
+int rcdm_conv_taps_gather(const void* P, int32_t ldp, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t upsample,
+                          const float* bias, void* out, int32_t ldc, void* stream) {
+  if (!P || !out || n_img <= 0 || h <= 0 || w <= 0 || c_out <= 0 || (upsample != 0 && upsample != 1)) return RCDM_EINVAL;
   if ((c_out & 7) || (ldp & 7) || (ldc & 7) || ldp < 9 * c_out || ldc < c_out) return RCDM_EINVAL;
   if ((((uintptr_t)P | (uintptr_t)out | (uintptr_t)bias) & 15)) return RCDM_EINVAL;
   if ((size_t)n_img * h * w * ldp * 2 >= (1ull << 31)) return RCDM_ESHAPE;   // 32-bit byte offsets into a 2-GB buffer resource
-  UpGatherArgs a{(const f16*)P, bias, (f16*)out, ldp, ldc, n_img, h, w, c_out};
-  const size_t total = (size_t)n_img * 4 * h * w * (c_out >> 3);
+  UpGatherArgs a{(const f16*)P, bias, (f16*)out, ldp, ldc, n_img, h, w, c_out, upsample};
+  const size_t total = ((size_t)n_img * h * w << (2 * upsample)) * (c_out >> 3);
   hipLaunchKernelGGL(upsample_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return rcdm_check_launch();
+}
+
+int rcdm_upsample_taps_gather(const void* P, int32_t ldp, int32_t n_img, int32_t h, int32_t w, int32_t c_out, const float* bias,
+                              void* out, int32_t ldc, void* stream) {
+  return rcdm_conv_taps_gather(P, ldp, n_img, h, w, c_out, 1, bias, out, ldc, stream);
 }
 
 int rcdm_set_wino_slab_f16(int32_t on) {

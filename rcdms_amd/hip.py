@@ -159,6 +159,7 @@ SYMBOLS = {
     "rcdm_pack_conv3x3_wino": (C.c_int, [_P, _I, _I, _P, _P]),
     "rcdm_set_wino_slab_f16": (C.c_int, [_I]),
     "rcdm_upsample_taps_gather": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "rcdm_conv_taps_gather": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "rcdm_set_splitk_slab_f16": (C.c_int, [_I]),
     "rcdm_conv3x3_wino": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                     C.POINTER(GroupNormDesc), _P, _P]),
@@ -530,6 +531,11 @@ def conv3x3_up2_supported(desc):
 def upsample_taps_gather(P, ldp, n_img, h, w, c_out, bias, out, ldc, stream=None):
     _check(load().rcdm_upsample_taps_gather(P, ldp, n_img, h, w, c_out, bias, out, ldc, stream_ptr() if stream is None else stream),
            "rcdm_upsample_taps_gather")
+
+
+def conv_taps_gather(P, ldp, n_img, h, w, c_out, upsample, bias, out, ldc, stream=None):
+    _check(load().rcdm_conv_taps_gather(P, ldp, n_img, h, w, c_out, upsample, bias, out, ldc, stream_ptr() if stream is None else stream),
+           "rcdm_conv_taps_gather")
 
 
 def set_splitk_slab_f16(on):

@@ -73,11 +73,14 @@ class Packer:
         self._tmp.append(w)
         return dst
 
-    def conv3x3_taps(self, key):
-        """Tap-plane weights of an Upsample3D conv (rcdm_gemm + rcdm_upsample_taps_gather): f16 [9 * cout][cin], row
-        tap * cout + c = weight[c][:][ky][kx]."""
+    def conv3x3_taps(self, key, cout_pad=None):
+        """Tap-plane weights of a conv3x3 (rcdm_gemm + rcdm_conv_taps_gather): f16 [9 * cout][cin], row tap * cout + c =
+        weight[c][:][ky][kx]; cout_pad: zero output channels appended first."""
         w = self.f32(key)
         cout, cin = w.shape[0], w.shape[1]
+        if cout_pad and cout_pad > cout:
+            w = torch.cat([w, torch.zeros(cout_pad - cout, cin, 3, 3, device=self.device)], dim=0).contiguous()
+            cout = cout_pad
         src = w.permute(2, 3, 0, 1).reshape(9 * cout, cin).contiguous()
         dst = torch.empty(9 * cout, cin, dtype=torch.float16, device=self.device)
         hip.pack_f16(src.data_ptr(), dst.data_ptr(), src.numel())

@@ -35,9 +35,10 @@ def wino_side(H, W):
 
 
 UP9 = _on("RCDM_UP9")                # 0: Upsample3D as four 2x2 phase convolutions (RCDM_UP2) instead of one 9-tap-plane GEMM + gather (resnet.py:60-79)
+OUT_TAPS = _on("RCDM_OUT_TAPS")      # 0: conv_out (320 -> 4 channels, unet.py:457) as the nine-tap implicit GEMM instead of a 72-wide tap-plane GEMM + gather
 CHAIN_MIN_ROWS = os.environ.get("RCDM_CHAIN_MIN_ROWS")   # token rows from which the chains are used (default: 3/4 of a chip of 160-row blocks)
 
 TABLE = {
     "RCDM_SC_FOLD": SC_FOLD, "RCDM_UP2": UP2, "RCDM_GN_PRESTAT": GN_PRESTAT, "RCDM_LNX": LNX, "RCDM_FFZ": FFZ,
-    "RCDM_FF_FUSE": FF_FUSE, "RCDM_ROWCHAIN": ROW_CHAIN, "RCDM_RANK1_CTX": RANK1_CTX, "RCDM_WINO": _w, "RCDM_UP9": UP9, "RCDM_CHAIN_MIN_ROWS": CHAIN_MIN_ROWS,
+    "RCDM_FF_FUSE": FF_FUSE, "RCDM_ROWCHAIN": ROW_CHAIN, "RCDM_RANK1_CTX": RANK1_CTX, "RCDM_WINO": _w, "RCDM_UP9": UP9, "RCDM_OUT_TAPS": OUT_TAPS, "RCDM_CHAIN_MIN_ROWS": CHAIN_MIN_ROWS,
 }

@@ -6,9 +6,10 @@ the reference recomputes them every step, attention.py:139-141), graph capture a
 import torch
 
 from . import hip
+from . import switches as SW
 from .emit_blocks import (CHAIN_MIN_ROWS, emit_ctx_kv, emit_motion, emit_rank1_ctx, emit_resnet, emit_transformer, wino_level,
                           full_rank_runs)
-from .emit_ops import XATTN_MAX_KEYS, emit_conv3x3, emit_groupnorm, emit_upsample_conv
+from .emit_ops import XATTN_MAX_KEYS, emit_conv3x3, emit_gemm, emit_groupnorm, emit_upsample_conv
 from .packer import Packer, pack_motion, pack_resnet, pack_transformer
 from .plan import Geo, Plan
 
@@ -277,11 +278,25 @@ class UNetProgram:
         emit_groupnorm(plan, final, b, frames * g0.hw, pk.vec("conv_norm_out.weight"), pk.vec("conv_norm_out.bias"),
                        eps, True, a, groups)
         self.out_channels = sd["conv_out.weight"].shape[0]
-        co_w = pk.conv3x3("conv_out.weight", cout_pad=COUT_PAD)
         co_b = torch.cat([pk.vec("conv_out.bias"),
                           torch.zeros(COUT_PAD - self.out_channels, device=self.device)]).contiguous()
         self.eps_out = plan.rows("eps_out", g0.M, COUT_PAD, unique=True)
-        emit_conv3x3(plan, a, g0.n_img, g0.H, g0.W, co_w, boc[0], COUT_PAD, self.eps_out, bias=co_b)
+        if SW.OUT_TAPS and boc[0] % 8 == 0 and g0.M * 9 * COUT_PAD * 2 < (1 << 31):
+            # 4 (padded 8) output channels waste 7/8 of the narrowest conv tile: nine tap planes of the pixels themselves as ONE
+            # GEMM with N = 72, then the gather that sums every pixel's nine neighbours' planes (rcdm_conv_taps_gather)
+            co_w9 = pk.conv3x3_taps("conv_out.weight", cout_pad=COUT_PAD)
+            P = plan.rows("out_taps", g0.M, 9 * COUT_PAD)
+            emit_gemm(plan, a, co_w9, 9 * COUT_PAD, boc[0], P)
+            eps_out = self.eps_out
+
+            def op_gather():
+                hip.conv_taps_gather(P.ptr, P.ld, g0.n_img, g0.H, g0.W, COUT_PAD, 0, co_b.data_ptr(), eps_out.ptr, eps_out.ld)
+            plan.add(op_gather, f"conv_gather {g0.n_img}x{g0.H}x{g0.W} C={COUT_PAD}")
+            plan.keep += [co_b]
+            plan.n_launch += 1
+        else:
+            co_w = pk.conv3x3("conv_out.weight", cout_pad=COUT_PAD)
+            emit_conv3x3(plan, a, g0.n_img, g0.H, g0.W, co_w, boc[0], COUT_PAD, self.eps_out, bias=co_b)
 
         pk.done()
         plan.materialize()

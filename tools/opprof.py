@@ -34,6 +34,9 @@ def algorithmic_work(tag):
         n, H, W = (float(v) for v in re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
         cin, cout = (float(v) for v in re.search(r"(\d+)->(\d+)", tag).groups())
         return 2e-9 * n * H * W * (9 * cin + kv.get("add1x1", 0.0)) * cout, None
+    if kind == "conv_gather":
+        n, H, W = (float(v) for v in re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
+        return None, 2e-6 * n * H * W * kv["C"] * (9 + 1)
     if kind == "upsample_gather":   # (its products are priced with the N = 9 c GEMM in front of it)
         n, H, W = (float(v) for v in re.search(r"(\d+)x(\d+)x(\d+)", tag).groups())
         return None, 2e-6 * n * H * W * kv["C"] * (9 + 4)
