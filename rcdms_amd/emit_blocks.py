@@ -60,7 +60,7 @@ def emit_resnet(plan, w, x, geo, temb, out, eps=1e-5, groups=32, out_scale=1.0, 
                  dup_rows=dup_rows, gn=out_gn)
 
 
-WINO_MIN_CHANNELS = int(__import__('os').environ.get('RCDM_WINO_MIN_C', '640'))   # k-loops of >= 10 steps per position GEMM; narrower convs keep the nine-tap form at every size
+WINO_MIN_CHANNELS = SW.WINO_MIN_C   # k-loops of >= 10 steps per position GEMM; narrower convs keep the nine-tap form at every size
 WINO_SHORTCUT_MIN_SIDE = 16   # below: a conv2 that carries a conv_shortcut keeps the nine-tap form (measured 49 against 47 us at 8x8)
 
 

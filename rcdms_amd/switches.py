@@ -24,6 +24,7 @@ RANK1_CTX = _on("RCDM_RANK1_CTX")    # 0: cross-attention evaluated in full even
 _w = os.environ.get("RCDM_WINO", "le32").strip()
 WINO_MAX_SIDE = int(_w[2:]) if _w.startswith("le") else 0
 WINO_MIN_SIDE = 8     # (below: 4 tiles per image, unmeasured)
+WINO_MIN_C = int(os.environ.get("RCDM_WINO_MIN_C", "640"))   # channels from which a conv takes the form (k-loops of >= 10 steps per position GEMM; 320: measured no gain)
 WINO = tuple(int(v) for v in _w.split(",") if v.strip().isdigit() and int(v) > 0) if not _w.startswith("le") else ()
 
 
@@ -40,5 +41,5 @@ CHAIN_MIN_ROWS = os.environ.get("RCDM_CHAIN_MIN_ROWS")   # token rows from which
 
 TABLE = {
     "RCDM_SC_FOLD": SC_FOLD, "RCDM_UP2": UP2, "RCDM_GN_PRESTAT": GN_PRESTAT, "RCDM_LNX": LNX, "RCDM_FFZ": FFZ,
-    "RCDM_FF_FUSE": FF_FUSE, "RCDM_ROWCHAIN": ROW_CHAIN, "RCDM_RANK1_CTX": RANK1_CTX, "RCDM_WINO": _w, "RCDM_UP9": UP9, "RCDM_OUT_TAPS": OUT_TAPS, "RCDM_CHAIN_MIN_ROWS": CHAIN_MIN_ROWS,
+    "RCDM_FF_FUSE": FF_FUSE, "RCDM_ROWCHAIN": ROW_CHAIN, "RCDM_RANK1_CTX": RANK1_CTX, "RCDM_WINO": _w, "RCDM_WINO_MIN_C": WINO_MIN_C, "RCDM_UP9": UP9, "RCDM_OUT_TAPS": OUT_TAPS, "RCDM_CHAIN_MIN_ROWS": CHAIN_MIN_ROWS,
 }

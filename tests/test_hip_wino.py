@@ -88,6 +88,7 @@ def _conv3x3_wino(hip, b, f, H, W, cin, cin2, cout, epi, split, gn, slab16):
     U = torch.empty(16, cout, cin, dtype=torch.float16, device=DEV)
     hip.pack_conv3x3_wino(w32.data_ptr(), cout, cin, U.data_ptr())
     bd, td, gd, bed = bias.to(DEV), temb.to(DEV), gamma.to(DEV), beta.to(DEV)
+    gd2, bd2 = (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * 0.3).to(DEV)
     M = b * f * H * W
     out = torch.full((M, cout), float("nan"), dtype=torch.float16, device=DEV)
     d = hip.ConvDesc(b * f, H, W, cin, cout, 1, 0, lda, cout, cout if epi & 4 else 0, epi, f * H * W, cout, 0.5, split, 0, 0, cin2,
@@ -119,6 +120,28 @@ def _conv3x3_wino(hip, b, f, H, W, cin, cin2, cout, epi, split, gn, slab16):
         hip.groupnorm_stats(god, out.data_ptr(), st_r.data_ptr(), gws2.data_ptr(), gws2.numel())
         torch.cuda.synchronize()
         assert torch.allclose(st_t, st_r, rtol=2e-5, atol=1e-6), (st_t - st_r).abs().max()
+        # ... and for a PER-FRAME norm behind the conv (attention.py:328 / motion_module.py:162: samples = images): same launch
+        gof = hip.GroupNormDesc(b * f, H * W, cout, 32, cout, cout, 1e-6, 0)
+        partf = ws(b * f * 32 * (H * W // 4) * 3 * 4)
+        out.fill_(float("nan"))
+        hip.conv3x3_wino(d, xd.data_ptr(), U.data_ptr(), bd.data_ptr() if epi & 1 else 0, td.data_ptr() if epi & 2 else 0,
+                         rd.data_ptr() if epi & 4 else 0, out.data_ptr(), wsb.data_ptr(), wsb.numel(),
+                         x2=x2d.data_ptr() if cin2 else 0, W2=w2d.data_ptr() if cin2 else 0, gn=gnd,
+                         gn_stat=stat.data_ptr() if gn else 0, gn_gamma=gd.data_ptr() if gn else 0, gn_beta=bed.data_ptr() if gn else 0,
+                         gn_out=gof, gn_out_partial=partf.data_ptr())
+        stf_t = torch.full((b * f * 32 * 2,), float("nan"), dtype=torch.float32, device=DEV)
+        hip.groupnorm_finalize(b * f, 32, H * W // 4, 1e-6, partf.data_ptr(), stf_t.data_ptr())
+        stf_r = torch.empty_like(stf_t)
+        gws3 = ws(hip.groupnorm_workspace_bytes(gof))
+        hip.groupnorm_stats(gof, out.data_ptr(), stf_r.data_ptr(), gws3.data_ptr(), gws3.numel())
+        # finalize + apply from those statistics == the norm's own three / single launch form
+        yn, yr = torch.empty_like(out), torch.empty_like(out)
+        hip.groupnorm_apply(gof, out.data_ptr(), stf_t.data_ptr(), gd2.data_ptr(), bd2.data_ptr(), yn.data_ptr())
+        gws4 = ws(hip.groupnorm_workspace_bytes(gof))
+        hip.groupnorm_silu(gof, out.data_ptr(), gd2.data_ptr(), bd2.data_ptr(), yr.data_ptr(), gws4.data_ptr(), gws4.numel())
+        torch.cuda.synchronize()
+        assert torch.allclose(stf_t, stf_r, rtol=2e-5, atol=1e-6), (stf_t - stf_r).abs().max()
+        assert (yn.float() - yr.float()).abs().max().item() <= 2e-3 * yr.float().abs().max().item() + 1e-3
     # the library's nine-tap form on the same operands (the norm + activation applied by its own launch)
     a1 = xd
     if gn:
