@@ -467,7 +467,7 @@ def main(argv=None):
     S, T = a.stories, a.ddim_steps
     cdim = a.width or 768
     story = synth.synthetic_story(stories=S, latent_hw=(a.latent, a.latent), ctx_len=a.ctx_len, ctx_dim=cdim, seed=42 + rank,
-                                  structure=a.context)
+                                  structure=a.context, cfg=a.guidance > 1)      # (--guidance <= 1: no unconditional half)
     if dist_on and a.guidance > 1:
         # the context every rank shares — the unconditional (empty-prompt) rows of the CFG batch are the same text for every
         # story — is built once on rank 0 and broadcast over RCCL / xGMI (north_star: "RCCL broadcast of the shared
