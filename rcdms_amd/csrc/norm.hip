@@ -227,6 +227,8 @@ struct GnFusedArgs {
   const float* beta;
   int P, cg, GB, NCHK, RPB, ldx, ldy, silu;
   float eps;
+  float* stat_out;   // non-null: statistics only — (mean, rstd) of the block's groups to stat_out[sample][group][2], no apply pass
+  int G;
 };
 
 __global__ __launch_bounds__(256) void gn_fused_kernel(const GnFusedArgs p) {
@@ -287,7 +289,13 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnFusedArgs p) {
     if (m2 < 0.f) m2 = 0.f;
     gstat[t * 2] = mean;
     gstat[t * 2 + 1] = rsqrtf(m2 / n + p.eps);  // biased variance, as torch.nn.GroupNorm
+    if (p.stat_out) {
+      float* o = p.stat_out + ((size_t)s * p.G + blockIdx.x * p.GB + t) * 2;
+      o[0] = gstat[t * 2];
+      o[1] = gstat[t * 2 + 1];
+    }
   }
+  if (p.stat_out) return;   // (rcdm_groupnorm_stats on a small tensor: one launch instead of statistics + finalize)
   __syncthreads();
   if (!live) return;
   float sc[8], sh[8];
@@ -677,6 +685,7 @@ int rcdm_groupnorm_silu(const rcdm_groupnorm_desc* d, const void* x, const float
       f.x = (const f16*)x; f.y = (f16*)y; f.gamma = gamma; f.beta = beta;
       f.P = a.P; f.cg = a.cg; f.GB = gb; f.NCHK = gb * a.cg / 8; f.RPB = 256 / f.NCHK;
       f.ldx = a.ldx; f.ldy = a.ldy; f.silu = a.silu; f.eps = a.eps;
+      f.stat_out = nullptr; f.G = a.G;
       hipLaunchKernelGGL(gn_fused_kernel, dim3(a.G / gb, a.samples), dim3(256), 0, stream0, f);
       return rcdm_check_launch();
     }
@@ -729,10 +738,20 @@ int rcdm_groupnorm_stats(const rcdm_groupnorm_desc* d, const void* x, float* sta
   if (rc) return rc;
   const size_t need = (size_t)a.samples * a.splits * a.G * 3 * sizeof(float);
   if (!workspace || workspace_bytes < need) return RCDM_EWORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (gn_single_launch(a)) {   // small tensor (<= 512 rows per sample): one block per (sample, group bundle) finalises by itself
+    const int gb = gn_fused_bundle(a.G, a.cg);
+    GnFusedArgs f;
+    f.x = (const f16*)x; f.y = nullptr; f.gamma = nullptr; f.beta = nullptr;
+    f.P = a.P; f.cg = a.cg; f.GB = gb; f.NCHK = gb * a.cg / 8; f.RPB = 256 / f.NCHK;
+    f.ldx = a.ldx; f.ldy = a.ldy; f.silu = 0; f.eps = a.eps;
+    f.stat_out = stat; f.G = a.G;
+    hipLaunchKernelGGL(gn_fused_kernel, dim3(a.G / gb, a.samples), dim3(256), 0, stream, f);
+    return rcdm_check_launch();
+  }
   a.x = (const f16*)x;
   a.partial = (float*)workspace;
   a.stat = stat;
-  hipStream_t stream = (hipStream_t)stream_;
   const int threads = a.CH * a.RPB;
   if (threads > 1024) return RCDM_ESHAPE;
   const size_t stats_lds = (size_t)(threads + a.CH) * 16 * sizeof(float);
